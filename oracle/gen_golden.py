@@ -1,0 +1,318 @@
+"""Pin the oracle to the reference and write tests/golden/*.npz.  DEVELOPMENT CONTAINER ONLY.
+
+Run:  python oracle/gen_golden.py            (needs /root/reference; never runs on the GPU box)
+
+What it does
+  1. imports the reference's `net` package from /root/reference (read-only, nothing copied);
+  2. loads this repo's deterministic parameters (oracle.make_params) into the reference modules;
+  3. asserts oracle == reference on CPU: HVIT / PHVIT forward bit-exact on random, uint8-quantised
+     and adversarial pixels; whole-network forward bit-exact; gradients equal to rounding; the
+     known-answer facts of SURVEY.md section 8c;
+  4. writes small fixtures (inputs + the REFERENCE's outputs/gradients) under tests/golden/.
+The fixtures are data only.  tests/test_oracle_golden.py re-checks the oracle against them on
+any machine; the GPU parity tests check the HIP path against them too.
+"""
+import os
+import sys
+
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from oracle import cidnet_oracle as O
+
+from net.CIDNet import CIDNet as RefCIDNet          # noqa: E402  (reference, imported not copied)
+from net.HVI_transform import RGB_HVI as RefHVI      # noqa: E402
+from net.LCA import HV_LCA as RefHVLCA, I_LCA as RefILCA  # noqa: E402
+from net.transformer_utils import NormDownsample as RefDown, NormUpsample as RefUp, LayerNorm as RefLN  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def adversarial_pixels() -> torch.Tensor:
+    """(1,3,1,N) image of hand-picked pixels: gray, black, white, primaries, all tie patterns."""
+    px = [
+        (0, 0, 0), (1, 1, 1), (.5, .5, .5), (1, 0, 0), (0, 1, 0), (0, 0, 1),
+        (.8, .8, .2), (.2, .8, .8), (.8, .2, .8),          # R=G>B, G=B>R, R=B>G
+        (.2, .2, .8), (.8, .2, .2), (.2, .8, .2),          # two-way min ties
+        (1, 1, 0), (0, 1, 1), (1, 0, 1),
+        (.3, .30000001, .3), (1e-9, 0, 0), (0, 1e-9, 0), (0, 0, 1e-9),
+        (.7, .1, .10000001), (.7, .10000001, .1),          # tiny +-(g-b): exercises the %6 wrap
+        (1e-4, 2e-4, 3e-4), (.999, .998, .997), (3 / 255, 3 / 255, 4 / 255),
+        (254 / 255, 1, 254 / 255), (.25, .5, .75), (.75, .5, .25), (.5, .75, .25),
+    ]
+    t = torch.tensor(px, dtype=torch.float32).t().reshape(1, 3, 1, len(px))
+    return t.contiguous()
+
+
+def adversarial_hvi() -> torch.Tensor:
+    """(1,3,1,N) HVI pixels for PHVIT: clamps on every side, the hi==6 black case, zeros."""
+    px = [
+        (1, -2e-8, .5),        # PHVIT -> (0,0,0)
+        (0, 0, 0), (0, 0, 1), (0, 0, .5), (1, 0, 1), (-1, 0, 1), (0, 1, 1), (0, -1, 1),
+        (2, 2, 2), (-2, -2, -1), (.3, .4, 1.5), (.3, .4, -.5), (.5, -.5, .7), (-.5, .5, .3),
+        (.05, .05, .01), (.9, .9, .99), (1e-9, 1e-9, .5), (-1e-9, -3e-8, .5), (.5, -1.5e-8, .25),
+        (.25, -1e-8, .8), (.1, .2, .3), (-.1, -.2, .3), (.6, -.01, .4), (-.6, .01, .4),
+    ]
+    return torch.tensor(px, dtype=torch.float32).t().reshape(1, 3, 1, len(px)).contiguous()
+
+
+def check_equal(a, b, what, exact=True, tol=0.0):
+    a, b = a.detach(), b.detach()
+    if exact:
+        same = torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())
+        assert same, f"{what}: oracle != reference (max abs diff {(a - b).abs().max().item():.3e})"
+    else:
+        d = (a - b).abs().max().item()
+        ref = b.abs().max().item()
+        assert d <= tol * max(ref, 1e-30) + 1e-12, f"{what}: diff {d:.3e} vs max {ref:.3e}"
+    print(f"  ok  {what}")
+
+
+def gen_hvi():
+    ref = RefHVI()
+    imgs = {
+        "rand": O.synthetic_batch(1, (2, 3, 24, 40)),
+        "quant": O.synthetic_batch(2, (2, 3, 24, 40), quantised=True),
+        "adv": adversarial_pixels(),
+    }
+    out = {}
+    for kval in (0.2, 0.37):
+        with torch.no_grad():
+            ref.density_k.fill_(kval)
+        k = ref.density_k.detach().clone()
+        for name, img in imgs.items():
+            x_ref = img.clone().requires_grad_(True)
+            y_ref = ref.HVIT(x_ref)
+            gy = O.synthetic_batch(7, tuple(y_ref.shape)) - 0.5
+            ref.density_k.grad = None
+            y_ref.backward(gy)
+            x_o = img.clone().requires_grad_(True)
+            k_o = k.clone().requires_grad_(True)
+            y_o = O.hvit(x_o, k_o)
+            y_o.backward(gy)
+            tag = f"{name}_k{kval}"
+            check_equal(y_o, y_ref, f"HVIT fwd {tag}")
+            check_equal(x_o.grad, x_ref.grad, f"HVIT d/dimg {tag}", exact=False, tol=1e-6)
+            check_equal(k_o.grad, ref.density_k.grad, f"HVIT d/dk {tag}", exact=False, tol=1e-5)
+            assert abs(ref.this_k - kval) < 1e-6
+            out[f"hvit_{tag}_in"] = img.numpy()
+            out[f"hvit_{tag}_out"] = y_ref.detach().numpy()
+            out[f"hvit_{tag}_gout"] = gy.numpy()
+            out[f"hvit_{tag}_gin"] = x_ref.grad.numpy()
+            out[f"hvit_{tag}_gk"] = ref.density_k.grad.numpy()
+            out[f"hvit_{tag}_code"] = O.hvit_branch_code(img).numpy()
+            # PHVIT on the HVIT output (round trip) with the same k (this_k side effect)
+            z_ref_in = y_ref.detach().clone().requires_grad_(True)
+            z_ref = ref.PHVIT(z_ref_in)
+            gz = O.synthetic_batch(8, tuple(z_ref.shape)) - 0.5
+            z_ref.backward(gz)
+            z_o_in = y_ref.detach().clone().requires_grad_(True)
+            z_o = O.phvit(z_o_in, ref.this_k)
+            z_o.backward(gz)
+            check_equal(z_o, z_ref, f"PHVIT(HVIT) fwd {tag}")
+            check_equal(z_o_in.grad, z_ref_in.grad, f"PHVIT(HVIT) bwd {tag}", exact=False, tol=1e-6)
+            out[f"phvit_rt_{tag}_out"] = z_ref.detach().numpy()
+            out[f"phvit_rt_{tag}_gout"] = gz.numpy()
+            out[f"phvit_rt_{tag}_gin"] = z_ref_in.grad.numpy()
+    # PHVIT on free-standing HVI inputs, all gating modes
+    hv_imgs = {
+        "rand": (O.synthetic_batch(3, (2, 3, 24, 40)) * 2.6 - 1.3),
+        "adv": adversarial_hvi(),
+    }
+    for kval in (0.0, 0.2):
+        for gated, gated2 in ((False, False), (True, True)):
+            ref.this_k = kval
+            ref.gated, ref.gated2, ref.alpha, ref.alpha_s = gated, gated2, 0.8, 1.3
+            for name, hv in hv_imgs.items():
+                a = hv.clone().requires_grad_(True)
+                y_ref = ref.PHVIT(a)
+                gy = O.synthetic_batch(9, tuple(y_ref.shape)) - 0.5
+                y_ref.backward(gy)
+                b = hv.clone().requires_grad_(True)
+                y_o = O.phvit(b, kval, gated, 1.3, gated2, 0.8)
+                y_o.backward(gy)
+                tag = f"{name}_k{kval}_g{int(gated)}"
+                check_equal(y_o, y_ref, f"PHVIT fwd {tag}")
+                check_equal(b.grad, a.grad, f"PHVIT bwd {tag}", exact=False, tol=1e-6)
+                out[f"phvit_{tag}_in"] = hv.numpy()
+                out[f"phvit_{tag}_out"] = y_ref.detach().numpy()
+                out[f"phvit_{tag}_gout"] = gy.numpy()
+                out[f"phvit_{tag}_gin"] = a.grad.numpy()
+                out[f"phvit_{tag}_hi"] = O.phvit_sextant(hv, kval).numpy()
+    ref.gated = ref.gated2 = False
+    # known-answer facts
+    fresh = RefHVI()
+    assert fresh.this_k == 0
+    ka = fresh.HVIT(torch.tensor([.8, .8, .2]).reshape(1, 3, 1, 1)).flatten().tolist()
+    assert abs(ka[0] - 0.3712552) < 1e-6 and abs(ka[1] - 0.6430328) < 1e-6 and abs(ka[2] - .8) < 1e-7, ka
+    blk = fresh.PHVIT(torch.tensor([1., -2e-8, .5]).reshape(1, 3, 1, 1)).flatten().tolist()
+    assert blk == [0.0, 0.0, 0.0], blk
+    np.savez_compressed(os.path.join(GOLD, "hvi_transform.npz"), **out)
+    print("wrote hvi_transform.npz", len(out), "arrays")
+
+
+def load_into(module: torch.nn.Module, p, prefix=""):
+    sd = {k: p[prefix + k] for k in module.state_dict().keys()}
+    module.load_state_dict(sd, strict=True)
+
+
+def gen_blocks():
+    """Per-block fixtures at reduced and full channel width (c/head = 18 in the full-width case)."""
+    out = {}
+    cases = [("w12", (12, 12, 24, 48), 2, (2, 20, 28)), ("w36", (36, 36, 72, 144), 2, (1, 16, 24))]
+    for tag, chans, heads, (B, H, W) in cases:
+        p = O.make_params(11, channels=chans)
+        C = chans[1]
+        # LayerNorm
+        ln = RefLN(C)
+        load_into(ln, p, "I_LCA1.norm.")
+        x = (O.synthetic_batch(21, (B, C, H, W)) - 0.5) * 3
+        xr = x.clone().requires_grad_(True)
+        yr = ln(xr)
+        gy = O.synthetic_batch(22, tuple(yr.shape)) - 0.5
+        yr.backward(gy)
+        xo = x.clone().requires_grad_(True)
+        po = O.params_to(p, requires_grad=True)
+        yo = O.layernorm_cf(xo, po["I_LCA1.norm.weight"], po["I_LCA1.norm.bias"])
+        yo.backward(gy)
+        check_equal(yo, yr, f"LayerNorm fwd {tag}")
+        check_equal(xo.grad, xr.grad, f"LayerNorm dx {tag}", exact=False, tol=1e-6)
+        out.update({f"ln_{tag}_x": x.numpy(), f"ln_{tag}_y": yr.detach().numpy(), f"ln_{tag}_gy": gy.numpy(),
+                    f"ln_{tag}_gx": xr.grad.numpy(), f"ln_{tag}_gw": ln.weight.grad.numpy(),
+                    f"ln_{tag}_gb": ln.bias.grad.numpy()})
+        # LCA blocks
+        for kind, Ref, fn in (("i_lca", RefILCA, O.i_lca), ("hv_lca", RefHVLCA, O.hv_lca)):
+            pre = "I_LCA1" if kind == "i_lca" else "HV_LCA1"
+            m = Ref(C, heads)
+            load_into(m, p, pre + ".")
+            x = O.synthetic_batch(31, (B, C, H, W)) - 0.5
+            y = O.synthetic_batch(32, (B, C, H, W)) - 0.5
+            xr, yr_ = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+            zr = m(xr, yr_)
+            gz = O.synthetic_batch(33, tuple(zr.shape)) - 0.5
+            zr.backward(gz)
+            po = O.params_to(p, requires_grad=True)
+            xo, yo_ = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+            zo = fn(xo, yo_, po, pre, heads)
+            zo.backward(gz)
+            check_equal(zo, zr, f"{kind} fwd {tag}")
+            check_equal(xo.grad, xr.grad, f"{kind} dx {tag}", exact=False, tol=1e-5)
+            check_equal(yo_.grad, yr_.grad, f"{kind} dy {tag}", exact=False, tol=1e-5)
+            out.update({f"{kind}_{tag}_x": x.numpy(), f"{kind}_{tag}_y": y.numpy(),
+                        f"{kind}_{tag}_out": zr.detach().numpy(), f"{kind}_{tag}_gout": gz.numpy(),
+                        f"{kind}_{tag}_gx": xr.grad.numpy(), f"{kind}_{tag}_gy": yr_.grad.numpy()})
+            for n, prm in m.named_parameters():
+                check_equal(po[pre + "." + n].grad, prm.grad, f"{kind} d{n} {tag}", exact=False, tol=2e-5)
+                out[f"{kind}_{tag}_g.{n}"] = prm.grad.numpy()
+        # down / up blocks (odd output size exercises floor(in/2) and the align_corners ratio)
+        dn = RefDown(chans[1], chans[2])
+        load_into(dn, p, "IE_block2.")
+        x = O.synthetic_batch(41, (B, chans[1], H + 2, W + 2)) - 0.5
+        xr = x.clone().requires_grad_(True)
+        yr = dn(xr)
+        gy = O.synthetic_batch(42, tuple(yr.shape)) - 0.5
+        yr.backward(gy)
+        po = O.params_to(p, requires_grad=True)
+        xo = x.clone().requires_grad_(True)
+        yo = O.norm_downsample(xo, po, "IE_block2")
+        yo.backward(gy)
+        check_equal(yo, yr, f"down fwd {tag}")
+        check_equal(xo.grad, xr.grad, f"down dx {tag}", exact=False, tol=1e-5)
+        out.update({f"down_{tag}_x": x.numpy(), f"down_{tag}_out": yr.detach().numpy(), f"down_{tag}_gout": gy.numpy(),
+                    f"down_{tag}_gx": xr.grad.numpy(), f"down_{tag}_g.prelu.weight": dn.prelu.weight.grad.numpy(),
+                    f"down_{tag}_g.down.0.weight": dn.down[0].weight.grad.numpy()})
+        up = RefUp(chans[2], chans[1])
+        load_into(up, p, "ID_block2.")
+        x = O.synthetic_batch(43, (B, chans[2], H // 2, W // 2)) - 0.5
+        sk = O.synthetic_batch(44, (B, chans[1], H // 2 * 2, W // 2 * 2)) - 0.5
+        xr, sr = x.clone().requires_grad_(True), sk.clone().requires_grad_(True)
+        yr = up(xr, sr)
+        gy = O.synthetic_batch(45, tuple(yr.shape)) - 0.5
+        yr.backward(gy)
+        po = O.params_to(p, requires_grad=True)
+        xo, so = x.clone().requires_grad_(True), sk.clone().requires_grad_(True)
+        yo = O.norm_upsample(xo, so, po, "ID_block2")
+        yo.backward(gy)
+        check_equal(yo, yr, f"up fwd {tag}")
+        check_equal(xo.grad, xr.grad, f"up dx {tag}", exact=False, tol=1e-5)
+        check_equal(so.grad, sr.grad, f"up dskip {tag}", exact=False, tol=1e-5)
+        out.update({f"up_{tag}_x": x.numpy(), f"up_{tag}_skip": sk.numpy(), f"up_{tag}_out": yr.detach().numpy(),
+                    f"up_{tag}_gout": gy.numpy(), f"up_{tag}_gx": xr.grad.numpy(), f"up_{tag}_gskip": sr.grad.numpy(),
+                    f"up_{tag}_g.prelu.weight": up.prelu.weight.grad.numpy(),
+                    f"up_{tag}_g.up_scale.0.weight": up.up_scale[0].weight.grad.numpy(),
+                    f"up_{tag}_g.up.weight": up.up.weight.grad.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **out)
+    print("wrote blocks.npz", len(out), "arrays")
+
+
+def gen_model():
+    """Whole-network fixtures: reduced width with all gradients; full width with output, selected
+    gradients and a checksum per gradient tensor; a strided sample of the 1x3x400x600 output."""
+    out = {}
+    cases = [("w12", (12, 12, 24, 48), (2, 3, 32, 48), False), ("w36", (36, 36, 72, 144), (1, 3, 64, 96), True)]
+    for tag, chans, shape, quant in cases:
+        p = O.make_params(5, channels=chans)
+        m = RefCIDNet(channels=list(chans))
+        load_into(m, p)
+        assert len(m.state_dict()) == 191
+        x = O.synthetic_batch(51, shape, quantised=quant)
+        gt = O.synthetic_batch(52, shape)
+        yr = m(x)
+        loss_r = (yr - gt).abs().mean()
+        loss_r.backward()
+        po = O.params_to(p, requires_grad=True)
+        yo = O.cidnet_forward(po, x)
+        loss_o = (yo - gt).abs().mean()
+        loss_o.backward()
+        check_equal(yo, yr, f"CIDNet fwd {tag}")
+        dead = [n for n, prm in m.named_parameters() if prm.grad is None]
+        assert all(n.startswith("I_LCA5.") for n in dead) and len(dead) == 13, dead
+        out[f"model_{tag}_x"] = x.numpy()
+        out[f"model_{tag}_gt"] = gt.numpy()
+        out[f"model_{tag}_out"] = yr.detach().numpy()
+        out[f"model_{tag}_loss"] = np.float64(loss_r.item())
+        worst = 0.0
+        for n, prm in m.named_parameters():
+            if prm.grad is None:
+                assert po[n].grad is None, n
+                continue
+            g_r, g_o = prm.grad, po[n].grad
+            d = (g_r - g_o).abs().max().item() / max(g_r.abs().max().item(), 1e-30)
+            worst = max(worst, d)
+            if tag == "w12" or n.count(".") <= 1 or "temperature" in n or n.startswith("HV_LCA3") or "norm" in n:
+                out[f"model_{tag}_g.{n}"] = g_r.numpy()
+            out[f"model_{tag}_gsum.{n}"] = np.array([g_r.double().sum().item(), g_r.double().abs().sum().item()])
+        print(f"  ok  CIDNet grads {tag}: worst rel-to-max diff oracle vs reference {worst:.2e}")
+        assert worst < 1e-4
+    # config-1 plumbing case: 1x3x400x600 forward, strided sample + checksums (default-init style params)
+    p = O.make_params(5, jitter=False)
+    m = RefCIDNet()
+    load_into(m, p)
+    x = O.synthetic_batch(61, (1, 3, 400, 600))
+    with torch.no_grad():
+        yr = m(x)
+        yo = O.cidnet_forward(p, x)
+    check_equal(yo, yr, "CIDNet fwd 1x3x400x600")
+    out["model_c1_out_strided"] = yr[:, :, ::16, ::16].numpy()
+    out["model_c1_out_sums"] = np.array([yr.double().sum().item(), yr.double().abs().sum().item(),
+                                         (yr.double() ** 2).sum().item()])
+    np.savez_compressed(os.path.join(GOLD, "model.npz"), **out)
+    print("wrote model.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    gen_hvi()
+    gen_blocks()
+    gen_model()
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
