@@ -1,0 +1,11 @@
+"""hvi-cidnet_amd: MI355X-native CIDNet forward/backward hot path.
+
+Hand-written gfx950 HIP kernels behind a C ABI (include/cidnet_hip.h, csrc/), wrapped as
+torch.autograd.Function ops (ops.py) and assembled into modules whose names, constructor arguments,
+attributes and state_dict keys equal the reference's net/CIDNet.py (cidnet.py, lca.py,
+transformer_utils.py, hvi_transform.py).  There is no CPU or ATen fallback: tensors must live on a
+ROCm device and libcidnet_hip.so must be built (`python hvi-cidnet_amd/build.py`).
+"""
+from . import _lib  # noqa: F401
+
+__all__ = ["_lib"]

@@ -1,0 +1,68 @@
+"""Builds libcidnet_hip.so (all csrc/*.hip, gfx950 only) in-tree with hipcc.
+
+    python hvi-cidnet_amd/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the development container; the
+resulting .so travels to the GPU box with the repository snapshot.  Objects are cached by mtime.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libcidnet_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC]
+# hvi.hip mirrors the reference's fp32 operation order (bit-exact masks/sextants): no implicit FMA
+PER_FILE = {"hvi.hip": ["-ffp-contract=off"]}
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    ts = [os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    ts += [os.path.getmtime(os.path.join(inc, f)) for f in os.listdir(inc)] if os.path.isdir(inc) else []
+    return max(ts) if ts else 0.0
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    spath = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(spath), _deps_mtime()):
+        return obj, False
+    cmd = [HIPCC, *COMMON, *PER_FILE.get(src, []), "-c", spath, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    if force or any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[build] linked {LIB} from {len(objs)} objects")
+    elif verbose:
+        print(f"[build] {LIB} up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,72 @@
+// Shared helpers for the CIDNet gfx950 kernels.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CIDNET_WAVE 64
+
+// ---- C-ABI status codes (include/cidnet_hip.h) -------------------------------------------
+#define CIDNET_OK 0
+#define CIDNET_ERR_ARG (-1)     // null pointer / non-positive size
+#define CIDNET_ERR_SHAPE (-2)   // shape the kernel family does not support
+#define CIDNET_ERR_WS (-3)      // workspace too small
+
+#define CIDNET_CHECK_ARG(cond) \
+  do {                         \
+    if (!(cond)) return CIDNET_ERR_ARG; \
+  } while (0)
+
+// launch + translate the (sticky-free) launch status into the ABI's int
+#define CIDNET_LAUNCH_STATUS()                           \
+  do {                                                   \
+    hipError_t e__ = hipGetLastError();                  \
+    if (e__ != hipSuccess) return (int)e__;              \
+  } while (0)
+
+namespace cidnet {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 4 floats with only dword alignment promised: hipcc emits global_load_dwordx4 /
+// global_store_dwordx4 for it on gfx950 (unaligned access mode), so rows whose byte offset is
+// not a multiple of 16 (e.g. 75- or 150-pixel rows) still move 16 B per lane.
+struct __attribute__((packed, aligned(4))) f4u {
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ f32x4 load4u(const float* p) {
+  f4u v = *reinterpret_cast<const f4u*>(p);
+  f32x4 r = {v.x, v.y, v.z, v.w};
+  return r;
+}
+__device__ __forceinline__ void store4u(float* p, f32x4 v) {
+  f4u s;
+  s.x = v[0]; s.y = v[1]; s.z = v[2]; s.w = v[3];
+  *reinterpret_cast<f4u*>(p) = s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over the block; result valid in thread 0.  `red` = LDS scratch of >= blockDim/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+  }
+  return t;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace cidnet

@@ -1,0 +1,35 @@
+"""CPU checks of the C-ABI boundary: the library builds for gfx950, loads, and exports every symbol
+that include/cidnet_hip.h declares (no kernel is launched here)."""
+import ctypes
+import os
+
+import pytest
+
+
+def test_header_parses_and_library_exports_every_symbol():
+    from hvi_cidnet_amd import _lib
+    protos = _lib.parse_header()
+    assert "cidnet_hvit_fwd" in protos and "cidnet_phvit_bwd" in protos
+    assert os.path.exists(_lib.LIB_PATH), "run `python hvi-cidnet_amd/build.py`"
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"libcidnet_hip.so lacks {name}"
+    assert _lib.lib().raw("cidnet_abi_version")() >= 1
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from hvi_cidnet_amd.hvi_transform import RGB_HVI
+    m = RGB_HVI()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.HVIT(torch.rand(1, 3, 4, 4))
+
+
+def test_product_package_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "hvi-cidnet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,94 @@
+"""CPU: the oracle (oracle/cidnet_oracle.py) reproduces the reference's outputs and gradients stored
+in tests/golden/*.npz (written by oracle/gen_golden.py from the imported reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cidnet_oracle as O
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _close(a, b, rel=1e-6, abs_=1e-7):
+    a, b = _t(a).double(), _t(b).double()
+    tol = rel * b.abs().max().item() + abs_
+    assert (a - b).abs().max().item() <= tol, ((a - b).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("name", ["rand", "quant", "adv"])
+@pytest.mark.parametrize("k", [0.2, 0.37])
+def test_hvit_matches_reference(golden, name, k):
+    g = golden("hvi_transform")
+    tag = f"{name}_k{k}"
+    x = _t(g[f"hvit_{tag}_in"]).requires_grad_(True)
+    kk = torch.full([1], k, requires_grad=True)
+    y = O.hvit(x, kk)
+    assert torch.equal(y.detach(), _t(g[f"hvit_{tag}_out"]))          # bit-exact forward on CPU
+    y.backward(_t(g[f"hvit_{tag}_gout"]))
+    _close(x.grad, g[f"hvit_{tag}_gin"])
+    _close(kk.grad, g[f"hvit_{tag}_gk"], rel=1e-5)
+    assert np.array_equal(O.hvit_branch_code(x.detach()).numpy(), g[f"hvit_{tag}_code"])
+    z = O.phvit(_t(g[f"hvit_{tag}_out"]), float(np.float32(k)))     # this_k = k.item() of the fp32 parameter
+    assert torch.equal(z, _t(g[f"phvit_rt_{tag}_out"]))
+
+
+@pytest.mark.parametrize("name", ["rand", "adv"])
+@pytest.mark.parametrize("k", [0.0, 0.2])
+@pytest.mark.parametrize("gated", [0, 1])
+def test_phvit_matches_reference(golden, name, k, gated):
+    g = golden("hvi_transform")
+    tag = f"{name}_k{k}_g{gated}"
+    x = _t(g[f"phvit_{tag}_in"]).requires_grad_(True)
+    y = O.phvit(x, k, bool(gated), 1.3, bool(gated), 0.8)
+    assert torch.equal(y.detach(), _t(g[f"phvit_{tag}_out"]))
+    y.backward(_t(g[f"phvit_{tag}_gout"]))
+    _close(x.grad, g[f"phvit_{tag}_gin"])
+    assert np.array_equal(O.phvit_sextant(x.detach(), k).numpy(), g[f"phvit_{tag}_hi"])
+
+
+def test_known_answers():
+    k = torch.full([1], 0.2)
+    px = lambda r, g, b: torch.tensor([r, g, b], dtype=torch.float32).reshape(1, 3, 1, 1)
+    assert O.hvit(px(0, 0, 0), k).flatten().tolist() == [0, 0, 0]
+    assert O.hvit(px(.5, .5, .5), k).flatten().tolist() == [0, 0, .5]
+    red = O.hvit(px(1, 0, 0), k).flatten()
+    assert torch.allclose(red, torch.tensor([1., 0., 1.]), atol=1e-6)
+    ka = O.hvit(px(.8, .8, .2), k).flatten()
+    assert torch.allclose(ka, torch.tensor([0.3712552, 0.6430328, 0.8]), atol=1e-6)
+    assert O.phvit(px(1., -2e-8, .5), 0.0).flatten().tolist() == [0, 0, 0]      # the hi == 6 black pixel
+    assert len(O.param_shapes()) == 191
+    assert sum(int(np.prod(s)) for s in O.param_shapes().values()) == 1975569
+
+
+@pytest.mark.parametrize("tag,chans", [("w12", (12, 12, 24, 48)), ("w36", (36, 36, 72, 144))])
+def test_model_matches_reference(golden, tag, chans):
+    g = golden("model")
+    p = O.params_to(O.make_params(5, channels=chans), requires_grad=True)
+    x, gt = _t(g[f"model_{tag}_x"]), _t(g[f"model_{tag}_gt"])
+    y = O.cidnet_forward(p, x)
+    assert torch.equal(y.detach(), _t(g[f"model_{tag}_out"]))
+    loss = (y - gt).abs().mean()
+    assert abs(loss.item() - float(g[f"model_{tag}_loss"])) < 1e-7
+    loss.backward()
+    for n, v in p.items():
+        key = f"model_{tag}_gsum.{n}"
+        if key not in g.files:
+            assert n.startswith("I_LCA5.") and v.grad is None
+            continue
+        s = g[key]
+        assert abs(v.grad.double().sum().item() - s[0]) <= 1e-6 * s[1] + 1e-12, n
+        if f"model_{tag}_g.{n}" in g.files:
+            _close(v.grad, g[f"model_{tag}_g.{n}"], rel=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["i_lca", "hv_lca"])
+def test_lca_blocks_match_reference(golden, kind):
+    g = golden("blocks")
+    for tag, chans in (("w12", (12, 12, 24, 48)), ("w36", (36, 36, 72, 144))):
+        p = O.make_params(11, channels=chans)
+        pre = "I_LCA1" if kind == "i_lca" else "HV_LCA1"
+        fn = O.i_lca if kind == "i_lca" else O.hv_lca
+        z = fn(_t(g[f"{kind}_{tag}_x"]), _t(g[f"{kind}_{tag}_y"]), p, pre, 2)
+        assert torch.equal(z, _t(g[f"{kind}_{tag}_out"]))
