@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CIDNet training step (forward + L1 loss + backward + gradient all-reduce +
+fused Adam) on synthetic 8x3x400x600 fp32 batches per GPU -- BASELINE.json config[1].
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = images/s over all ranks (weak scaling: 8 images per rank).
+`roofline` is measured live with HIP events (torch.cuda.Event on the launch stream) around every
+launch of the dominant kernel family in extra, separately-run steps; `cpu_baseline` times the CPU
+oracle (oracle/cidnet_oracle.py, a port of the reference's algorithm) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=400)
+    ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
+    return ap.parse_args()
+
+
+class OpTimer:
+    """Times every C-ABI call with an event pair (diagnostic pass only, never the timed region)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        from hvi_cidnet_amd import _lib
+        L = _lib.lib()
+        self._orig = L.call
+        timer = self
+
+        def timed(name, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            timer._orig(name, *args)
+            e1.record()
+            timer.rec.append((name, args, e0, e1))
+        L.call = timed
+        return self
+
+    def remove(self):
+        from hvi_cidnet_amd import _lib
+        _lib.lib().call = self._orig
+
+    def table(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, args, e0, e1 in self.rec:
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+        return agg
+
+
+def conv3x3_flops(args):
+    # cidnet_conv3x3(X, x_bs, Wt, w_ms, w_ks, flip, replicate, Y, y_bs, B, M, K, H, W, stream)
+    B, M, K, H, W = args[9], args[10], args[11], args[12], args[13]
+    return 2.0 * 9 * M * K * H * W * B
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+
+    torch.manual_seed(0)
+    model = P.CIDNet().to(dev)
+    trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    shape = (a.batch, 3, a.height, a.width)
+    x = torch.rand(shape, device=dev, generator=g)
+    gt = torch.rand(shape, device=dev, generator=g)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 1)):
+        loss = trainer.step(x, gt)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.step(x, gt)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    lossv = float(loss.item())
+    assert lossv == lossv, "loss is NaN"
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (dense 3x3 conv on the fp32 MFMA), live events --
+        timer = OpTimer().install()
+        for _ in range(2):
+            trainer.step(x, gt)
+        agg = timer.table()
+        timer.remove()
+        tot = sum(v[1] for v in agg.values())
+        c3 = [(args, e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if name == "cidnet_conv3x3"]
+        c3_flops = sum(conv3x3_flops(ar) for ar, _ in c3)
+        c3_ms = sum(ms for _, ms in c3)
+        achieved = c3_flops / (c3_ms * 1e-3) / 1e12 if c3_ms > 0 else 0.0
+        if a.op_table:
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {k:40s} calls/step {v[0] // 2:5d}  ms/step {v[1] / 2:9.3f}  {100 * v[1] / tot:5.1f}%", file=sys.stderr)
+            print(f"  sum of kernel families: {tot / 2:.3f} ms/step; wall {1e3 * dt / a.steps:.3f} ms/step", file=sys.stderr)
+        roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad)",
+                "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
+                "share_of_step_kernel_time": round(c3_ms / tot, 3) if tot else None}
+
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(a)
+
+        out = {
+            "metric": "images/sec fwd+bwd, CIDNet 400x600 bs=8 (step = fwd + L1 loss + bwd + grad all-reduce + Adam)",
+            "value": round(world * a.batch * a.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CIDNet fwd+bwd bs={a.batch}/GPU 3x{a.height}x{a.width} fp32 (BASELINE.json configs[1])",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": round(lossv, 6)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a):
+    """The oracle (port of the reference algorithm, plain PyTorch CPU eager) forward+backward on a
+    bounded sample: 2 images of the same 3xHxW shape (1/4 of one GPU batch), all host cores."""
+    from oracle import cidnet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = O.params_to(O.make_params(0, jitter=False), requires_grad=True)
+    n = 2
+    x = O.synthetic_batch(1, (n, 3, a.height, a.width))
+    gt = O.synthetic_batch(2, (n, 3, a.height, a.width))
+    y = O.cidnet_forward(p, x[:1, :, :64, :96])          # page-in / thread-pool warm-up
+    y.abs().mean().backward()
+    t0 = time.perf_counter()
+    y = O.cidnet_forward(p, x)
+    (y - gt).abs().mean().backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 fwd+bwd of {n}x3x{a.height}x{a.width} fp32, torch CPU eager, {cores} threads ({dt:.1f} s)"}
+
+
+if __name__ == "__main__":
+    main()

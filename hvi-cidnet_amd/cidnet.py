@@ -1,0 +1,129 @@
+"""`CIDNet`: drop-in for the reference's net/CIDNet.py module (same constructor, attribute `trans`,
+method `HVIT`, 191 state_dict keys) running entirely on the hand-written gfx950 kernels."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .hvi_transform import RGB_HVI
+from .lca import HV_LCA, I_LCA
+from .transformer_utils import NormDownsample, NormUpsample
+
+try:  # the reference mixes this in for from_pretrained/save_pretrained (net/CIDNet.py:6,8)
+    from huggingface_hub import PyTorchModelHubMixin as _HubMixin
+except Exception:  # pragma: no cover - hub client not installed
+    class _HubMixin:  # type: ignore
+        pass
+
+
+class _RepConv(nn.Sequential):
+    """ReplicationPad2d(1) + Conv2d(3x3, padding=0) container (keys `<name>.1.weight`) whose forward
+    is the fused replicate-border conv kernel."""
+
+    def __init__(self, cin, cout):
+        super().__init__(nn.ReplicationPad2d(1), nn.Conv2d(cin, cout, 3, stride=1, padding=0, bias=False))
+
+    def forward(self, x):
+        return ops.RepConv3x3Fn.apply(x, self[1].weight)
+
+
+class CIDNet(nn.Module, _HubMixin):
+    """Reference: net/CIDNet.py:8-126."""
+
+    def __init__(self, channels=[36, 36, 72, 144], heads=[1, 2, 4, 8], norm=False):
+        super().__init__()
+        [ch1, ch2, ch3, ch4] = channels
+        [head1, head2, head3, head4] = heads
+
+        # HV_ways
+        self.HVE_block0 = _RepConv(3, ch1)
+        self.HVE_block1 = NormDownsample(ch1, ch2, use_norm=norm)
+        self.HVE_block2 = NormDownsample(ch2, ch3, use_norm=norm)
+        self.HVE_block3 = NormDownsample(ch3, ch4, use_norm=norm)
+
+        self.HVD_block3 = NormUpsample(ch4, ch3, use_norm=norm)
+        self.HVD_block2 = NormUpsample(ch3, ch2, use_norm=norm)
+        self.HVD_block1 = NormUpsample(ch2, ch1, use_norm=norm)
+        self.HVD_block0 = _RepConv(ch1, 2)
+
+        # I_ways
+        self.IE_block0 = _RepConv(1, ch1)
+        self.IE_block1 = NormDownsample(ch1, ch2, use_norm=norm)
+        self.IE_block2 = NormDownsample(ch2, ch3, use_norm=norm)
+        self.IE_block3 = NormDownsample(ch3, ch4, use_norm=norm)
+
+        self.ID_block3 = NormUpsample(ch4, ch3, use_norm=norm)
+        self.ID_block2 = NormUpsample(ch3, ch2, use_norm=norm)
+        self.ID_block1 = NormUpsample(ch2, ch1, use_norm=norm)
+        self.ID_block0 = _RepConv(ch1, 1)
+
+        self.HV_LCA1 = HV_LCA(ch2, head2)
+        self.HV_LCA2 = HV_LCA(ch3, head3)
+        self.HV_LCA3 = HV_LCA(ch4, head4)
+        self.HV_LCA4 = HV_LCA(ch4, head4)
+        self.HV_LCA5 = HV_LCA(ch3, head3)
+        self.HV_LCA6 = HV_LCA(ch2, head2)
+
+        self.I_LCA1 = I_LCA(ch2, head2)
+        self.I_LCA2 = I_LCA(ch3, head3)
+        self.I_LCA3 = I_LCA(ch4, head4)
+        self.I_LCA4 = I_LCA(ch4, head4)
+        self.I_LCA5 = I_LCA(ch3, head3)     # parameters kept for checkpoint parity; see forward()
+        self.I_LCA6 = I_LCA(ch2, head2)
+
+        self.trans = RGB_HVI()
+
+    def forward(self, x):
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise RuntimeError(f"CIDNet: H and W must be multiples of 8 (got {tuple(x.shape[2:])}); the reference "
+                               "fails in NormUpsample's cat for other sizes (net/transformer_utils.py:64)")
+        hvi = self.trans.HVIT(x)
+        i = hvi[:, 2:3, :, :].contiguous()
+        # low
+        i_enc0 = self.IE_block0(i)
+        i_enc1 = self.IE_block1(i_enc0)
+        hv_0 = self.HVE_block0(hvi)
+        hv_1 = self.HVE_block1(hv_0)
+        i_jump0 = i_enc0
+        hv_jump0 = hv_0
+
+        i_enc2 = self.I_LCA1(i_enc1, hv_1)
+        hv_2 = self.HV_LCA1(hv_1, i_enc1)
+        v_jump1 = i_enc2
+        hv_jump1 = hv_2
+        i_enc2 = self.IE_block2(i_enc2)
+        hv_2 = self.HVE_block2(hv_2)
+
+        v_jump2 = self.I_LCA2(i_enc2, hv_2)
+        hv_jump2 = self.HV_LCA2(hv_2, i_enc2)
+        i_enc3 = self.IE_block3(i_enc2)      # reference quirk: level-3 encoders take the PRE-LCA2
+        hv_3 = self.HVE_block3(hv_2)         # tensors (net/CIDNet.py:94-95)
+
+        i_enc4 = self.I_LCA3(i_enc3, hv_3)
+        hv_4 = self.HV_LCA3(hv_3, i_enc3)
+
+        i_dec4 = self.I_LCA4(i_enc4, hv_4)
+        hv_4 = self.HV_LCA4(hv_4, i_enc4)
+
+        hv_3 = self.HVD_block3(hv_4, hv_jump2)
+        i_dec3 = self.ID_block3(i_dec4, v_jump2)
+        # net/CIDNet.py:105 evaluates I_LCA5(i_dec3, hv_3) and :109 then ignores it (ID_block2 is fed
+        # i_dec3): the result never reaches the output and its 13 parameters get no gradient, so the
+        # dead block is not executed here.
+        hv_2 = self.HV_LCA5(hv_3, i_dec3)
+
+        hv_2 = self.HVD_block2(hv_2, hv_jump1)
+        i_dec2 = self.ID_block2(i_dec3, v_jump1)
+
+        i_dec1 = self.I_LCA6(i_dec2, hv_2)
+        hv_1 = self.HV_LCA6(hv_2, i_dec2)
+
+        i_dec1 = self.ID_block1(i_dec1, i_jump0)
+        i_dec0 = self.ID_block0(i_dec1)
+        hv_1 = self.HVD_block1(hv_1, hv_jump0)
+        hv_0 = self.HVD_block0(hv_1)
+
+        # cat([hv_0, i_dec0], 1) + hvi -> PHVIT, fused (net/CIDNet.py:119-120)
+        return self.trans.PHVIT_residual(hv_0, i_dec0, hvi)
+
+    def HVIT(self, x):
+        return self.trans.HVIT(x)

@@ -1,0 +1,429 @@
+// K9/K10/K11: dense 3x3 convolution (pad 1: zero or replicate) as an implicit GEMM on the fp32
+// MFMA (v_mfma_f32_16x16x4_f32) -- forward, data gradient (same kernel: flipped taps, transposed
+// weight strides), weight gradient, and the border correction of the replicate-pad data gradient.
+// Reference call sites: net/transformer_utils.py:39,58 (zero pad) and net/CIDNet.py:21-24,32-35,
+// 39-42,50-53 (ReplicationPad2d(1) + valid conv).
+//
+// Forward mapping (no activation goes through LDS):
+//   lane l = (c = l&15, j = l>>4).  For a k-group of 4 input channels (channel = group*4 + j) and an
+//   input row, the lane loads the float4 X[ch][row][x0+4c .. +3]; its left/right neighbours come from
+//   lanes c-1 / c+1 by DPP row shifts (lanes 0 / 15 fetch the tile halo).  Element e+dx of that
+//   6-wide window is the B operand (k = j, col = c) of the MFMA for tap (dy,dx) and pixel slot e, so
+//   the accumulators e = 0..3 of an output channel hold 4 consecutive pixels: float4 stores.
+//   One loaded input row feeds up to 3 output rows x 3 dx x 4 slots x MT channel tiles of MFMAs.
+//   Weights (A operand) are staged per 16-channel chunk in LDS as [ci][tap][co] with a leading
+//   dimension == 16 (mod 32): conflict-free ds_read_b32.
+#include "common.h"
+
+namespace cidnet {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kR = 2;      // output rows per wave
+constexpr int kKC = 16;    // input channels staged per chunk (4 k-groups)
+
+struct C3Args {
+  const float* X; long x_bs;
+  const float* Wt; long w_ms, w_ks;   // A[m][k][tap] = Wt[m*w_ms + k*w_ks + tap']
+  float* Y; long y_bs;
+  int M, K, H, W;
+  int flip;        // tap' = 8 - tap (data gradient)
+  int replicate;   // border mode of the input
+  int nmb;         // number of m-blocks (blockIdx.z = b*nmb + mb)
+};
+
+__device__ __forceinline__ float dpp_row_shr1(float src, float old) {   // lane c <- lane c-1 (c>0); lane 0 keeps old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                               0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_row_shl1(float src, float old) {   // lane c <- lane c+1 (c<15); lane 15 keeps old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                               0x101, 0xF, 0xF, false));
+}
+
+struct Win6 {
+  float v[6];
+};
+
+// window x0-1 .. x0+4 of one input row for this lane's channel; `chan_ok` false => zeros
+__device__ __forceinline__ Win6 load_win(const float* __restrict__ plane, int yy, int x0, int c, int H, int W, bool chan_ok,
+                                         bool replicate) {
+  Win6 r;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = 0.f;
+  bool row_ok = chan_ok;
+  if (yy < 0 || yy >= H) {
+    if (replicate) yy = yy < 0 ? 0 : H - 1; else row_ok = false;
+  }
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};
+  float el = 0.f, er = 0.f;
+  if (row_ok) {
+    const float* row = plane + (long)yy * W;
+    if (x0 + 3 < W) {
+      m = load4u(row + x0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        if (x < W) m[e] = row[x]; else if (replicate) m[e] = row[W - 1];
+      }
+    }
+    if (c == 0) {
+      if (x0 > 0) el = row[x0 - 1]; else if (replicate) el = row[0];
+    }
+    if (c == 15) {
+      if (x0 + 4 < W) er = row[x0 + 4]; else if (replicate) er = row[W - 1];
+    }
+  }
+  r.v[1] = m[0]; r.v[2] = m[1]; r.v[3] = m[2]; r.v[4] = m[3];
+  r.v[0] = dpp_row_shr1(m[3], el);
+  r.v[5] = dpp_row_shl1(m[0], er);
+  return r;
+}
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
+  extern __shared__ float As[];                 // [kKC][9][ldA]
+  constexpr int MB = 16 * MT;
+  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, j = lane >> 4;
+  const int b = blockIdx.z / a.nmb, mb = blockIdx.z - b * a.nmb;
+  const int m0 = mb * MB;
+  const int x0 = blockIdx.x * 64 + 4 * c;
+  const int yw = blockIdx.y * (4 * kR) + wave * kR;      // first output row of this wave
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  const float* Xb = a.X + (long)b * a.x_bs;
+  const bool rep = a.replicate != 0;
+
+  f32x4 acc[kR][MT][4];
+#pragma unroll
+  for (int r = 0; r < kR; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r][mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc0 = 0; kc0 < a.K; kc0 += kKC) {
+    const int kcn = min(kKC, a.K - kc0);
+    const int ng = (kcn + 3) >> 2;
+    __syncthreads();
+    for (int i = tid; i < ng * 4 * 9 * MB; i += kThreads) {
+      const int mm = i % MB;
+      const int t = (i / MB) % 9;
+      const int kk = i / (MB * 9);
+      float v = 0.f;
+      if (kk < kcn && m0 + mm < a.M)
+        v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
+      As[(kk * 9 + t) * ldA + mm] = v;
+    }
+    __syncthreads();
+    if (yw >= H) continue;                     // wave-uniform; still takes part in the barriers above
+    for (int g = 0; g < ng; ++g) {
+      const int ch = kc0 + 4 * g + j;
+      const bool chan_ok = (4 * g + j) < kcn;
+      const float* plane = Xb + (long)(chan_ok ? ch : 0) * HW;
+      Win6 win[kR + 2];
+#pragma unroll
+      for (int iy = 0; iy < kR + 2; ++iy) win[iy] = load_win(plane, yw - 1 + iy, x0, c, H, W, chan_ok, rep);
+      float av[9][MT];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[((g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
+#pragma unroll
+      for (int iy = 0; iy < kR + 2; ++iy)
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+          const int dy = iy - r;
+          if (dy < 0 || dy > 2) continue;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[r][mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dy * 3 + dx][mt], win[iy].v[e + dx], acc[r][mt][e], 0, 0, 0);
+        }
+    }
+  }
+
+  if (x0 >= W) return;
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int y = yw + r;
+    if (y >= H) continue;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + mt * 16 + j * 4 + reg;
+        if (m >= a.M) continue;
+        float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
+        const f32x4 v = {acc[r][mt][0][reg], acc[r][mt][1][reg], acc[r][mt][2][reg], acc[r][mt][3][reg]};
+        if (x0 + 3 < W) {
+          store4u(row + x0, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (x0 + e < W) row[x0 + e] = v[e];
+        }
+      }
+  }
+}
+
+template <int MT>
+int launch_c3(const C3Args& a, int B, hipStream_t s) {
+  constexpr int MB = 16 * MT;
+  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  const size_t lds = (size_t)kKC * 9 * ldA * sizeof(float);
+  dim3 grid((unsigned)((a.W + 63) / 64), (unsigned)((a.H + 4 * kR - 1) / (4 * kR)), (unsigned)(B * a.nmb));
+  hipLaunchKernelGGL((conv3_kernel<MT>), grid, dim3(kThreads), lds, s, a);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dW[m][n][dy][dx] = sum_{b,y,x} dY[b][m][y][x] * Xpad[b][n][y+dy-1][x+dx-1]
+// A operand = dY rows (16 output channels x 4 k-slots), B operand = X rows shifted by the tap; the
+// k-slot (j, e) <-> pixel xs + 8j + e of image row y.  A wave sweeps a 32-pixel-wide column of rows
+// with a 3-row sliding window of X, holding all 9 taps x MT x 1 accumulator tiles.
+// ---------------------------------------------------------------------------------------------
+struct C3WgArgs {
+  const float* dY; long dy_bs;
+  const float* X; long x_bs;
+  float* slabs;     // [B][chunks][4][M*N*9]
+  int M, N, H, W;
+  int replicate;
+  int rr;           // rows per chunk
+  int nseg4;        // ceil(nseg / 4): x-segment groups
+  int nnt;          // number of 16-wide n tiles
+};
+
+struct Win10 {
+  float v[10];
+};
+
+__device__ __forceinline__ Win10 load_win10(const float* __restrict__ plane, int yy, int xs, int H, int W, bool ok,
+                                            bool replicate) {
+  Win10 r;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r.v[i] = 0.f;
+  if (yy < 0 || yy >= H) {
+    if (replicate) yy = yy < 0 ? 0 : H - 1; else ok = false;
+  }
+  if (!ok) return r;
+  const float* row = plane + (long)yy * W;
+  if (xs >= 1 && xs + 8 < W) {
+    const f32x4 a = load4u(row + xs), b = load4u(row + xs + 4);
+    r.v[0] = row[xs - 1];
+    r.v[1] = a[0]; r.v[2] = a[1]; r.v[3] = a[2]; r.v[4] = a[3];
+    r.v[5] = b[0]; r.v[6] = b[1]; r.v[7] = b[2]; r.v[8] = b[3];
+    r.v[9] = row[xs + 8];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      int x = xs - 1 + i;
+      if (x < 0) { if (replicate) x = 0; else continue; }
+      if (x >= W) { if (replicate) x = W - 1; else continue; }
+      r.v[i] = row[x];
+    }
+  }
+  return r;
+}
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, j = lane >> 4;
+  const int b = blockIdx.z;
+  const int mb = blockIdx.y / a.nnt, nt = blockIdx.y - mb * a.nnt;
+  const int m0 = mb * 16 * MT, n0 = nt * 16;
+  const int segg = blockIdx.x % a.nseg4, rchunk = blockIdx.x / a.nseg4;
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  const int xs = ((segg * 4 + wave) * 32) + 8 * j;         // this lane's first pixel of the segment
+  const bool seg_ok = (segg * 4 + wave) * 32 < W;
+  const int ya = rchunk * a.rr, yb = min(ya + a.rr, H);
+  const bool rep = a.replicate != 0;
+
+  f32x4 acc[9][MT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (seg_ok) {
+    const int n = n0 + r;
+    const bool n_ok = n < a.N;
+    const float* xpl = a.X + (long)b * a.x_bs + (long)(n_ok ? n : 0) * HW;
+    Win10 w0 = load_win10(xpl, ya - 1, xs, H, W, n_ok, rep);
+    Win10 w1 = load_win10(xpl, ya, xs, H, W, n_ok, rep);
+    for (int y = ya; y < yb; ++y) {
+      const Win10 w2 = load_win10(xpl, y + 1, xs, H, W, n_ok, rep);
+      float av[MT][8];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + mt * 16 + r;
+        const float* row = a.dY + (long)b * a.dy_bs + (long)(m < a.M ? m : 0) * HW + (long)y * W;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[mt][e] = 0.f;
+        if (m < a.M) {
+          if (xs + 7 < W) {
+            const f32x4 p = load4u(row + xs), q = load4u(row + xs + 4);
+            av[mt][0] = p[0]; av[mt][1] = p[1]; av[mt][2] = p[2]; av[mt][3] = p[3];
+            av[mt][4] = q[0]; av[mt][5] = q[1]; av[mt][6] = q[2]; av[mt][7] = q[3];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (xs + e < W) av[mt][e] = row[xs + e];
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            acc[dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w0.v[e + dx], acc[dx][mt], 0, 0, 0);
+            acc[3 + dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w1.v[e + dx], acc[3 + dx][mt], 0, 0, 0);
+            acc[6 + dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w2.v[e + dx], acc[6 + dx][mt], 0, 0, 0);
+          }
+      w0 = w1; w1 = w2;
+    }
+  }
+
+  float* slab = a.slabs + ((((long)b * gridDim.x + blockIdx.x) * 4 + wave) * (long)a.M) * a.N * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + mt * 16 + j * 4 + reg, n = n0 + r;
+        if (m < a.M && n < a.N) slab[((long)m * a.N + n) * 9 + t] = acc[t][mt][reg];
+      }
+}
+
+__global__ void c3_reduce_kernel(const float* __restrict__ slabs, int n_red, long ne, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  float t0 = 0.f, t1 = 0.f;
+  int k = 0;
+  for (; k + 1 < n_red; k += 2) { t0 += slabs[(long)k * ne + i]; t1 += slabs[(long)(k + 1) * ne + i]; }
+  if (k < n_red) t0 += slabs[(long)k * ne + i];
+  out[i] = t0 + t1;
+}
+
+inline int wg_rows(int H) { return H >= 200 ? 64 : 32; }
+
+// Border correction of the data gradient of (ReplicationPad2d(1) + valid 3x3 conv): the zero-pad
+// data gradient misses the taps that read a replicated border pixel; add them in place.
+// gX[b][ci][u][v] += sum_co sum_{(y,dy),(x,dx) with at least one clamped coordinate} W[co][ci][dy][dx] * gY[b][co][y][x]
+__global__ void c3_replicate_fix_kernel(const float* __restrict__ gY, const float* __restrict__ Wt, float* __restrict__ gX,
+                                        int B, int Co, int Ci, int H, int W) {
+  const int nb = 2 * W + 2 * (H - 2 > 0 ? H - 2 : 0);     // border pixels
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * Ci * nb) return;
+  const int k = (int)(idx % nb);
+  const int ci = (int)((idx / nb) % Ci);
+  const int b = (int)(idx / ((long)nb * Ci));
+  int u, v;
+  if (k < W) { u = 0; v = k; }
+  else if (k < 2 * W) { u = H - 1; v = k - W; }
+  else { const int t = k - 2 * W; u = 1 + (t >> 1); v = (t & 1) ? W - 1 : 0; }
+  if (H == 1 && k >= W) return;
+  if (W == 1 && k >= 2 * W && (k & 1)) return;
+  const long HW = (long)H * W;
+  float s = 0.f;
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      // all (y, x) whose padded tap (y+dy-1, x+dx-1) clamps onto (u, v)
+      for (int cy = 0; cy < 2; ++cy) {          // cy = 1: clamped row coordinate
+        int y;
+        if (cy == 0) { y = u - dy + 1; if (y < 0 || y >= H) continue; }
+        else { if (u == 0 && dy == 0) y = 0; else if (u == H - 1 && dy == 2) y = H - 1; else continue; }
+        for (int cx = 0; cx < 2; ++cx) {
+          int x;
+          if (cx == 0) { x = v - dx + 1; if (x < 0 || x >= W) continue; }
+          else { if (v == 0 && dx == 0) x = 0; else if (v == W - 1 && dx == 2) x = W - 1; else continue; }
+          if (cy == 0 && cx == 0) continue;     // the unclamped tap is in the zero-pad gradient already
+          for (int co = 0; co < Co; ++co)
+            s += Wt[((long)co * Ci + ci) * 9 + dy * 3 + dx] * gY[((long)b * Co + co) * HW + (long)y * W + x];
+        }
+      }
+    }
+  gX[((long)b * Ci + ci) * HW + (long)u * W + v] += s;
+}
+
+}  // namespace
+}  // namespace cidnet
+
+using namespace cidnet;
+
+extern "C" {
+
+int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, int replicate, float* Y,
+                   long y_bs, int B, int M, int K, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(X && Wt && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
+  C3Args a{};
+  a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs;
+  a.M = M; a.K = K; a.H = H; a.W = W; a.flip = flip; a.replicate = replicate;
+  const int T = (M + 15) / 16;
+  const int nblk = (T + 2) / 3;
+  const int MT = (T + nblk - 1) / nblk;
+  a.nmb = (T + MT - 1) / MT;
+  hipStream_t s = (hipStream_t)stream;
+  switch (MT) {
+    case 1: return launch_c3<1>(a, B, s);
+    case 2: return launch_c3<2>(a, B, s);
+    default: return launch_c3<3>(a, B, s);
+  }
+}
+
+long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W) {
+  const int rr = wg_rows(H);
+  const long chunks = (long)(((W + 31) / 32 + 3) / 4) * ((H + rr - 1) / rr);
+  return (long)B * chunks * 4 * M * N * 9;
+}
+
+int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int replicate, float* dW, float* ws,
+                         long ws_floats, int B, int M, int N, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && H > 0 && W > 0);
+  if (ws_floats < cidnet_conv3x3_wgrad_ws_floats(B, M, N, H, W)) return CIDNET_ERR_WS;
+  C3WgArgs a{};
+  a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.H = H; a.W = W;
+  a.replicate = replicate; a.rr = wg_rows(H);
+  a.nseg4 = ((W + 31) / 32 + 3) / 4;
+  a.nnt = (N + 15) / 16;
+  const int chunks = a.nseg4 * ((H + a.rr - 1) / a.rr);
+  const int T = (M + 15) / 16;
+  const int nblk = (T + 2) / 3;
+  const int MT = (T + nblk - 1) / nblk;
+  const int nmb = (T + MT - 1) / MT;
+  dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnt), (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+  if (MT == 1) hipLaunchKernelGGL((conv3_wgrad_kernel<1>), grid, dim3(kThreads), 0, s, a);
+  else if (MT == 2) hipLaunchKernelGGL((conv3_wgrad_kernel<2>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((conv3_wgrad_kernel<3>), grid, dim3(kThreads), 0, s, a);
+  CIDNET_LAUNCH_STATUS();
+  const long ne = (long)M * N * 9;
+  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, ws, B * chunks * 4, ne, dW);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_conv3x3_replicate_dgrad_fix(const float* gY, const float* Wt, float* gX, int B, int Co, int Ci, int H, int W,
+                                       void* stream) {
+  CIDNET_CHECK_ARG(gY && Wt && gX && B > 0 && Co > 0 && Ci > 0 && H > 0 && W > 0);
+  const long nb = 2L * W + 2L * (H - 2 > 0 ? H - 2 : 0);
+  const long total = (long)B * Ci * nb;
+  hipLaunchKernelGGL(c3_replicate_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gY, Wt,
+                     gX, B, Co, Ci, H, W);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// K5 / K8 stencil parts: depthwise 3x3 convolution (zero pad 1) forward / data-gradient (flipped
+// taps) / weight-gradient, and the IEL gate  g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2)
+// forward and backward (reference: net/LCA.py:14,16,53-55,62-65).
+//
+// All kernels share one tiling: a lane owns a 4-pixel-wide, kRows-tall column strip of one (b,c)
+// plane and slides a 3-row register window down it, so each input row is fetched once per strip
+// (+2 halo rows per 8) as one 16 B load plus two neighbour scalars that hit L1.  16 adjacent lanes
+// cover 64 contiguous pixels of a row.  HBM-bound by construction (2 FLOP per byte).
+#include "common.h"
+
+namespace cidnet {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRows = 8;
+
+struct Row6 {
+  float v[6];
+};
+
+// pixels x0-1 .. x0+4 of row yy of a plane (zero outside the image)
+__device__ __forceinline__ Row6 load_row6(const float* __restrict__ plane, int yy, int x0, int H, int W) {
+  Row6 r;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = 0.f;
+  if (yy < 0 || yy >= H) return r;
+  const float* row = plane + (long)yy * W;
+  if (x0 + 3 < W) {
+    const f32x4 m = load4u(row + x0);
+    r.v[1] = m[0]; r.v[2] = m[1]; r.v[3] = m[2]; r.v[4] = m[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (x0 + e < W) r.v[1 + e] = row[x0 + e];
+  }
+  if (x0 > 0) r.v[0] = row[x0 - 1];
+  if (x0 + 4 < W) r.v[5] = row[x0 + 4];
+  return r;
+}
+
+__device__ __forceinline__ void store_row4(float* __restrict__ plane, int y, int x0, int W, f32x4 v) {
+  float* row = plane + (long)y * W;
+  if (x0 + 3 < W) {
+    store4u(row + x0, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (x0 + e < W) row[x0 + e] = v[e];
+  }
+}
+
+__device__ __forceinline__ f32x4 stencil(const Row6& a, const Row6& b, const Row6& c, const float* w) {
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    o[e] = w[0] * a.v[e] + w[1] * a.v[e + 1] + w[2] * a.v[e + 2] + w[3] * b.v[e] + w[4] * b.v[e + 1] + w[5] * b.v[e + 2] +
+           w[6] * c.v[e] + w[7] * c.v[e + 1] + w[8] * c.v[e + 2];
+  return o;
+}
+
+struct Item {
+  long bc;
+  int y0, x0;
+  bool live;
+};
+
+// flattened work decomposition: ((bc * nstrips + strip) * nxg + xg) * 16 + xl
+__device__ __forceinline__ Item decode_item(long planes, int H, int W) {
+  const int nxg = (((W + 3) >> 2) + 15) >> 4;
+  const int nstrips = (H + kRows - 1) / kRows;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  Item it;
+  const long xl = idx & 15;
+  long rest = idx >> 4;
+  const long xg = rest % nxg; rest /= nxg;
+  const long strip = rest % nstrips;
+  it.bc = rest / nstrips;
+  it.y0 = (int)strip * kRows;
+  it.x0 = (int)(xg * 16 + xl) * 4;
+  it.live = it.bc < planes && it.x0 < W;
+  return it;
+}
+
+inline long n_items(long planes, int H, int W) {
+  const long nxg = (((W + 3) >> 2) + 15) >> 4;
+  const long nstrips = (H + kRows - 1) / kRows;
+  return planes * nstrips * nxg * 16;
+}
+
+__device__ __forceinline__ void load_w9(const float* w1, const float* w2, int csplit, int c, bool flip, float* w) {
+  const float* src = (c < csplit) ? w1 + (long)c * 9 : w2 + (long)(c - csplit) * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = src[flip ? 8 - t : t];
+}
+
+// out = dwconv3x3(in) [+ addend]
+__global__ __launch_bounds__(kThreads) void dw3x3_kernel(const float* __restrict__ in, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, int csplit,
+                                                         const float* __restrict__ addend, float* __restrict__ out, int flip,
+                                                         int B, int C, int H, int W) {
+  const Item it = decode_item((long)B * C, H, W);
+  if (!it.live) return;
+  float w[9];
+  load_w9(w1, w2, csplit, (int)(it.bc % C), flip != 0, w);
+  const long HW = (long)H * W;
+  const float* ip = in + it.bc * HW;
+  float* op = out + it.bc * HW;
+  const float* ap = addend ? addend + it.bc * HW : nullptr;
+  Row6 r0 = load_row6(ip, it.y0 - 1, it.x0, H, W);
+  Row6 r1 = load_row6(ip, it.y0, it.x0, H, W);
+  const int yend = min(it.y0 + kRows, H);
+  for (int y = it.y0; y < yend; ++y) {
+    const Row6 r2 = load_row6(ip, y + 1, it.x0, H, W);
+    f32x4 o = stencil(r0, r1, r2, w);
+    if (ap) {
+      const Row6 a = load_row6(ap, y, it.x0, H, W);
+      o[0] += a.v[1]; o[1] += a.v[2]; o[2] += a.v[3]; o[3] += a.v[4];
+    }
+    store_row4(op, y, it.x0, W, o);
+    r0 = r1; r1 = r2;
+  }
+}
+
+// IEL gate.  u: (B, 2h, H, W); channel c pairs u1 = u[c], u2 = u[h + c].
+// MODE 0: g = s1*s2.   MODE 1 (backward): da = dg * s_other * (1 - t^2), ds = dg * s_other.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restrict__ u, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, const float* __restrict__ dg,
+                                                            float* __restrict__ g, float* __restrict__ da,
+                                                            float* __restrict__ ds, int B, int h, int H, int W) {
+  const Item it = decode_item((long)B * h, H, W);
+  if (!it.live) return;
+  const int c = (int)(it.bc % h);
+  const long b = it.bc / h;
+  float wa[9], wb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { wa[t] = w1[(long)c * 9 + t]; wb[t] = w2[(long)c * 9 + t]; }
+  const long HW = (long)H * W;
+  const float* p1 = u + (b * 2 * h + c) * HW;
+  const float* p2 = u + (b * 2 * h + h + c) * HW;
+  Row6 a0 = load_row6(p1, it.y0 - 1, it.x0, H, W), a1 = load_row6(p1, it.y0, it.x0, H, W);
+  Row6 b0 = load_row6(p2, it.y0 - 1, it.x0, H, W), b1 = load_row6(p2, it.y0, it.x0, H, W);
+  const int yend = min(it.y0 + kRows, H);
+  for (int y = it.y0; y < yend; ++y) {
+    const Row6 a2 = load_row6(p1, y + 1, it.x0, H, W);
+    const Row6 b2 = load_row6(p2, y + 1, it.x0, H, W);
+    const f32x4 c1 = stencil(a0, a1, a2, wa), c2 = stencil(b0, b1, b2, wb);
+    f32x4 t1, t2, s1, s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t1[e] = tanhf(c1[e]); t2[e] = tanhf(c2[e]);
+      s1[e] = t1[e] + a1.v[1 + e]; s2[e] = t2[e] + b1.v[1 + e];
+    }
+    if (MODE == 0) {
+      store_row4(g + it.bc * HW, y, it.x0, W, s1 * s2);
+    } else {
+      const Row6 gr = load_row6(dg + it.bc * HW, y, it.x0, H, W);
+      f32x4 d1, d2, e1, e2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d1[e] = gr.v[1 + e] * s2[e]; d2[e] = gr.v[1 + e] * s1[e];
+        e1[e] = d1[e] * (1.f - t1[e] * t1[e]); e2[e] = d2[e] * (1.f - t2[e] * t2[e]);
+      }
+      store_row4(ds + (b * 2 * h + c) * HW, y, it.x0, W, d1);
+      store_row4(ds + (b * 2 * h + h + c) * HW, y, it.x0, W, d2);
+      store_row4(da + (b * 2 * h + c) * HW, y, it.x0, W, e1);
+      store_row4(da + (b * 2 * h + h + c) * HW, y, it.x0, W, e2);
+    }
+    a0 = a1; a1 = a2; b0 = b1; b1 = b2;
+  }
+}
+
+// gw[c][t] partial over one block of strips of plane (b,c):  sum gout[y][x] * in[y+dy-1][x+dx-1]
+__global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                               float* __restrict__ part, int H, int W, int nchunk) {
+  __shared__ float red[kThreads / 64];
+  const int nxg = (((W + 3) >> 2) + 15) >> 4;
+  const int nstrips = (H + kRows - 1) / kRows;
+  const long bc = blockIdx.y;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // item inside the plane
+  const int xl = (int)(idx & 15);
+  const long rest = idx >> 4;
+  const int xg = (int)(rest % nxg), strip = (int)(rest / nxg);
+  const int x0 = (xg * 16 + xl) * 4, y0 = strip * kRows;
+  const bool live = strip < nstrips && x0 < W;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  if (live) {
+    const long HW = (long)H * W;
+    const float* ip = in + bc * HW;
+    const float* gp = gout + bc * HW;
+    Row6 r0 = load_row6(ip, y0 - 1, x0, H, W), r1 = load_row6(ip, y0, x0, H, W);
+    const int yend = min(y0 + kRows, H);
+    for (int y = y0; y < yend; ++y) {
+      const Row6 r2 = load_row6(ip, y + 1, x0, H, W);
+      const Row6 gr = load_row6(gp, y, x0, H, W);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gv = gr.v[1 + e];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          acc[dx] += gv * r0.v[e + dx]; acc[3 + dx] += gv * r1.v[e + dx]; acc[6 + dx] += gv * r2.v[e + dx];
+        }
+      }
+      r0 = r1; r1 = r2;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float s = block_sum(acc[t], red);
+    if (threadIdx.x == 0) part[(bc * nchunk + blockIdx.x) * 9 + t] = s;
+  }
+}
+
+// gw[c][t] (+)= sum_b sum_chunk part[((b*C + c)*nchunk + chunk)*9 + t]
+__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int B, int C, int nchunk, float* __restrict__ gw1,
+                                       float* __restrict__ gw2, int csplit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 9) return;
+  const int c = i / 9, t = i - c * 9;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < nchunk; ++k) s += part[(((long)b * C + c) * nchunk + k) * 9 + t];
+  if (c < csplit) gw1[(long)c * 9 + t] = s; else gw2[(long)(c - csplit) * 9 + t] = s;
+}
+
+inline int wgrad_chunks(int H, int W) {
+  const long nxg = (((W + 3) >> 2) + 15) >> 4;
+  const long nstrips = (H + kRows - 1) / kRows;
+  return (int)((nstrips * nxg * 16 + kThreads - 1) / kThreads);
+}
+
+}  // namespace
+}  // namespace cidnet
+
+using namespace cidnet;
+
+extern "C" {
+
+int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend, float* out, int flip,
+                 int B, int C, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(in && w1 && out && B > 0 && C > 0 && H > 0 && W > 0);
+  CIDNET_CHECK_ARG(csplit >= C || w2);
+  const long items = n_items((long)B * C, H, W);
+  hipLaunchKernelGGL(dw3x3_kernel, dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, in, w1, w2, csplit, addend, out, flip, B, C, H, W);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h, int H, int W,
+                        void* stream) {
+  CIDNET_CHECK_ARG(u && w1 && w2 && g && B > 0 && h > 0 && H > 0 && W > 0);
+  const long items = n_items((long)B * h, H, W);
+  hipLaunchKernelGGL((iel_gate_kernel<0>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, u, w1, w2, (const float*)nullptr, g, (float*)nullptr, (float*)nullptr, B, h, H, W);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_iel_gate_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* da, float* ds, int B,
+                        int h, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(u && w1 && w2 && dg && da && ds && B > 0 && h > 0 && H > 0 && W > 0);
+  const long items = n_items((long)B * h, H, W);
+  hipLaunchKernelGGL((iel_gate_kernel<1>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, u, w1, w2, dg, (float*)nullptr, da, ds, B, h, H, W);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W) { return (long)B * C * wgrad_chunks(H, W) * 9; }
+
+int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw2, int csplit, float* ws, long ws_floats,
+                       int B, int C, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(in && gout && gw1 && ws && B > 0 && C > 0 && H > 0 && W > 0);
+  CIDNET_CHECK_ARG(csplit >= C || gw2);
+  if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
+  const int nchunk = wgrad_chunks(H, W);
+  hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(kThreads), 0, (hipStream_t)stream,
+                     in, gout, ws, H, W, nchunk);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B,
+                     C, nchunk, gw1, gw2, csplit);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+}  // extern "C"

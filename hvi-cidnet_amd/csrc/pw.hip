@@ -1,0 +1,354 @@
+// K4: pointwise (1x1) convolution as an fp32-MFMA GEMM over NCHW planes -- forward, data gradient
+// (same kernel, transposed weight strides), per-sample weights (the attention AV*project_out
+// fold), fused epilogues (residual add; bilinear x2 add + PReLU of NormUpsample), and the weight
+// gradient (split-K over pixels into slabs + fixed-order slab reduction).
+//
+// Reference call sites: net/LCA.py:13,15,17,22-23,40,51,57,61,66 and net/transformer_utils.py:60,66.
+//
+// GEMM view per sample:  Y[M x HW] = A[M x K] * X[K x HW],  HW contiguous.
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32).  Operand placement is chosen so that NO activation
+// goes through LDS and every global access is 16 B per lane:
+//   lane l = (c = l&15, j = l>>4) loads the float4 X[k0+j][p0+4c .. p0+4c+3]; element e of it is
+//   the B operand (k = j, col = c) of MFMA #e, whose output columns are the pixels {p0+4c+e}.
+//   After the K loop, register `reg` of the four accumulators e=0..3 holds Y[row][p0+4c+0..3]:
+//   one float4 store per lane.  16 lanes cover 256 contiguous bytes of a plane row.
+// Weights (A operand) are tiny and staged once per K-chunk in LDS, k-major with a leading
+// dimension == 16 (mod 32) so the two k-rows of a 32-lane half hit disjoint banks.
+#include "common.h"
+
+namespace cidnet {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kKC = 128;   // K rows staged per chunk
+
+struct PwArgs {
+  const float* X; long x_bs;
+  const float* Wt; long w_bs, w_ms, w_ks;
+  float* Y; long y_bs;
+  const float* R; long r_bs;
+  const float* Z; int zh, zw;
+  const float* slope;
+  float* Ypre;
+  int M, K; long HW; int W;
+};
+
+__device__ __forceinline__ f32x4 load_px4(const float* row, long p, long HW, bool valid) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid && p < HW) {
+    if (p + 3 < HW) {
+      v = load4u(row + p);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (p + e < HW) v[e] = row[p + e];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_px4(float* row, long p, long HW, f32x4 v) {
+  if (p + 3 < HW) {
+    store4u(row + p, v);
+  } else {
+    for (int e = 0; e < 4; ++e)
+      if (p + e < HW) row[p + e] = v[e];
+  }
+}
+
+struct UpTap {
+  int o00, o01, o10, o11;
+  float lx, ly;
+};
+
+// bilinear, align_corners=True, exactly x2 output (nn.UpsamplingBilinear2d, transformer_utils.py:59)
+__device__ __forceinline__ UpTap up_tap(long p, int W, int zh, int zw) {
+  const int H = 2 * zh;
+  const int y = (int)(p / W), x = (int)(p - (long)y * W);
+  const float sh = (H > 1) ? (float)(zh - 1) / (float)(H - 1) : 0.f;
+  const float sw = (W > 1) ? (float)(zw - 1) / (float)(W - 1) : 0.f;
+  const float fy = sh * (float)y, fx = sw * (float)x;
+  const int y0 = (int)fy, x0 = (int)fx;
+  UpTap t;
+  t.ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f);
+  t.lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+  const int y1 = y0 + (y0 < zh - 1 ? 1 : 0), x1 = x0 + (x0 < zw - 1 ? 1 : 0);
+  t.o00 = y0 * zw + x0; t.o01 = y0 * zw + x1; t.o10 = y1 * zw + x0; t.o11 = y1 * zw + x1;
+  return t;
+}
+
+// EPI: 0 plain, 1 + residual R, 2 + bilinear_x2(Z) then PReLU (writes optional pre-activation)
+template <int MT, int EPI>
+__global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
+  extern __shared__ float As[];
+  constexpr int MB = 16 * MT;
+  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, j = lane >> 4;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * MB;
+  const long p0 = (long)blockIdx.x * 256 + wave * 64 + 4 * c;
+  const long HW = a.HW;
+  const float* Xb = a.X + (long)b * a.x_bs;
+  const float* Wb = a.Wt + (long)b * a.w_bs;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc0 = 0; kc0 < a.K; kc0 += kKC) {
+    const int kcn = min(kKC, a.K - kc0);
+    const int kcn4 = (kcn + 3) & ~3;
+    __syncthreads();
+    for (int i = tid; i < kcn4 * MB; i += kThreads) {
+      const int kk = i / MB, mm = i - kk * MB;
+      float v = 0.f;
+      if (kk < kcn && m0 + mm < a.M) v = Wb[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks];
+      As[kk * ldA + mm] = v;
+    }
+    __syncthreads();
+    f32x4 xv = load_px4(Xb + (long)(kc0 + j) * HW, p0, HW, j < kcn);
+    for (int k4 = 0; k4 < kcn4; k4 += 4) {
+      const f32x4 xc = xv;
+      if (k4 + 4 < kcn4) xv = load_px4(Xb + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av = As[(k4 + j) * ldA + mt * 16 + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+      }
+    }
+  }
+
+  if (p0 >= HW) return;
+  UpTap tap[4];
+  float slope = 0.f;
+  if (EPI == 2) {
+    slope = a.slope[0];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tap[e] = up_tap(p0 + e < HW ? p0 + e : HW - 1, a.W, a.zh, a.zw);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = m0 + mt * 16 + j * 4 + reg;
+      if (m >= a.M) continue;
+      f32x4 v = {acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
+      if (EPI == 1) v += load_px4(a.R + (long)b * a.r_bs + (long)m * HW, p0, HW, true);
+      if (EPI == 2) {
+        const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const UpTap& t = tap[e];
+          const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
+          const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
+          v[e] += (1.f - t.ly) * top + t.ly * bot;
+        }
+        if (a.Ypre) store_px4(a.Ypre + (long)b * a.y_bs + (long)m * HW, p0, HW, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+      }
+      store_px4(a.Y + (long)b * a.y_bs + (long)m * HW, p0, HW, v);
+    }
+  }
+}
+
+template <int MT>
+int launch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
+  constexpr int MB = 16 * MT;
+  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  const int kc = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
+  const size_t lds = (size_t)kc * ldA * sizeof(float);
+  dim3 grid((unsigned)((a.HW + 255) / 256), (unsigned)((a.M + MB - 1) / MB), (unsigned)B);
+  if (epi == 0) hipLaunchKernelGGL((pw_conv_kernel<MT, 0>), grid, dim3(kThreads), lds, s, a);
+  else if (epi == 1) hipLaunchKernelGGL((pw_conv_kernel<MT, 1>), grid, dim3(kThreads), lds, s, a);
+  else hipLaunchKernelGGL((pw_conv_kernel<MT, 2>), grid, dim3(kThreads), lds, s, a);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int dispatch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
+  const int T = (a.M + 15) / 16;
+  const int nblk = (T + 5) / 6;
+  const int MT = (T + nblk - 1) / nblk;
+  switch (MT) {
+    case 1: return launch_pw<1>(a, epi, B, s);
+    case 2: return launch_pw<2>(a, epi, B, s);
+    case 3: return launch_pw<3>(a, epi, B, s);
+    case 4: return launch_pw<4>(a, epi, B, s);
+    case 5: return launch_pw<5>(a, epi, B, s);
+    default: return launch_pw<6>(a, epi, B, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dW[m][n] = sum_{b,p} dY[b][m][p] * X[b][n][p]
+// Both MFMA operands are "row = channel, k = pixel", so both are plain float4 loads along the
+// pixel axis; the k-slot permutation (lane j, element e) <-> pixel p + 8j + e is shared by A and B.
+// Each wave owns a pixel sub-range and a private accumulator tile, written to its own slab.
+// ---------------------------------------------------------------------------------------------
+struct WgArgs {
+  const float* dY; long dy_bs;
+  const float* X; long x_bs;
+  float* slabs;         // [B][chunks][4 waves][M*N]
+  int M, N; long HW; int pch;   // pixels per block (multiple of 128)
+  int nnb;              // number of n-blocks
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, j = lane >> 4;
+  const int b = blockIdx.z;
+  const int mb = blockIdx.y / a.nnb, nb = blockIdx.y - mb * a.nnb;
+  const int m0 = mb * 16 * MT, n0 = nb * 16 * NT;
+  const long HW = a.HW;
+  const long pbeg = (long)blockIdx.x * a.pch;
+  const long pend = (pbeg + a.pch < HW) ? pbeg + a.pch : HW;
+  const float* dYb = a.dY + (long)b * a.dy_bs;
+  const float* Xb = a.X + (long)b * a.x_bs;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (long p = pbeg + wave * 32; p < pend; p += 128) {
+    const long pl = p + 8 * j;
+    f32x4 av[MT][2], bv[NT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + r;
+      const float* row = dYb + (long)m * HW;
+      av[mt][0] = load_px4(row, pl, pend, m < a.M);
+      av[mt][1] = load_px4(row, pl + 4, pend, m < a.M);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + nt * 16 + r;
+      const float* row = Xb + (long)n * HW;
+      bv[nt][0] = load_px4(row, pl, pend, n < a.N);
+      bv[nt][1] = load_px4(row, pl + 4, pend, n < a.N);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][h][e], bv[nt][h][e], acc[mt][nt], 0, 0, 0);
+  }
+
+  float* slab = a.slabs + ((((long)b * gridDim.x + blockIdx.x) * 4 + wave) * (long)a.M) * a.N;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + mt * 16 + j * 4 + reg, n = n0 + nt * 16 + r;
+        if (m < a.M && n < a.N) slab[(long)m * a.N + n] = acc[mt][nt][reg];
+      }
+}
+
+// out[o][m*ld + n] (+)= sum_r slabs[(o*n_red + r)][m*N + n]   -- fixed order => reproducible
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_red, int M, int N, float* __restrict__ out,
+                                    long out_os, long out_ld, int accumulate) {
+  const long ne = (long)M * N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ne) return;
+  const int o = blockIdx.y;
+  const float* s = slabs + (long)o * n_red * ne + i;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int rr = 0;
+  for (; rr + 3 < n_red; rr += 4) {
+    t0 += s[(long)rr * ne]; t1 += s[(long)(rr + 1) * ne]; t2 += s[(long)(rr + 2) * ne]; t3 += s[(long)(rr + 3) * ne];
+  }
+  for (; rr < n_red; ++rr) t0 += s[(long)rr * ne];
+  const int m = (int)(i / N), n = (int)(i - (long)m * N);
+  float* dst = out + (long)o * out_os + (long)m * out_ld + n;
+  const float v = (t0 + t1) + (t2 + t3);
+  *dst = accumulate ? *dst + v : v;
+}
+
+template <int MT, int NT>
+int launch_wg(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
+  dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnb), (unsigned)B);
+  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), grid, dim3(kThreads), 0, s, a);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+inline int pick_tiles(int dim, int maxt) {   // tiles per block for a dimension of `dim` channels
+  const int T = (dim + 15) / 16;
+  const int nblk = (T + maxt - 1) / maxt;
+  return (T + nblk - 1) / nblk;
+}
+
+inline int wgrad_pch(long HW) { return HW >= 16384 ? 2048 : 512; }
+
+}  // namespace
+}  // namespace cidnet
+
+using namespace cidnet;
+
+extern "C" {
+
+int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
+                   const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {
+  CIDNET_CHECK_ARG(X && Wt && Y && B > 0 && M > 0 && K > 0 && HW > 0);
+  PwArgs a{};
+  a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_bs = w_bs; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs;
+  a.R = R; a.r_bs = r_bs; a.M = M; a.K = K; a.HW = HW;
+  return dispatch_pw(a, R ? 1 : 0, B, (hipStream_t)stream);
+}
+
+int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, const float* Z,
+                            const float* slope, float* Y, float* Ypre, int B, int M, int K, int zh, int zw,
+                            void* stream) {
+  CIDNET_CHECK_ARG(X && Wt && Z && slope && Y && B > 0 && M > 0 && K > 0 && zh > 0 && zw > 0);
+  PwArgs a{};
+  a.HW = 4L * zh * zw; a.W = 2 * zw;
+  a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_bs = 0; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = (long)M * a.HW;
+  a.Z = Z; a.zh = zh; a.zw = zw; a.slope = slope; a.Ypre = Ypre; a.M = M; a.K = K;
+  return dispatch_pw(a, 2, B, (hipStream_t)stream);
+}
+
+long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW) {
+  const int pch = wgrad_pch(HW);
+  const long chunks = (HW + pch - 1) / pch;
+  return (long)B * chunks * 4 * M * N;
+}
+
+int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld, int per_sample,
+                    int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
+  CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && HW > 0);
+  if (ws_floats < cidnet_pw_wgrad_ws_floats(B, M, N, HW)) return CIDNET_ERR_WS;
+  WgArgs a{};
+  a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.HW = HW;
+  a.pch = wgrad_pch(HW);
+  const int chunks = (int)((HW + a.pch - 1) / a.pch);
+  const int MT = pick_tiles(M, 3), NT = pick_tiles(N, 3);
+  const int nmb = ((M + 15) / 16 + MT - 1) / MT;
+  a.nnb = ((N + 15) / 16 + NT - 1) / NT;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+#define WG_CASE(mt, nt) if (MT == mt && NT == nt) rc = launch_wg<mt, nt>(a, chunks, nmb, B, s); else
+  WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(3, 1) WG_CASE(3, 2)
+  WG_CASE(3, 3) rc = CIDNET_ERR_SHAPE;
+#undef WG_CASE
+  if (rc != CIDNET_OK) return rc;
+  const long ne = (long)M * N;
+  dim3 grid((unsigned)((ne + 255) / 256), per_sample ? (unsigned)B : 1u);
+  const int n_red = per_sample ? chunks * 4 : B * chunks * 4;
+  hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, s, ws, n_red, M, N, dW, (long)M * dw_ld, dw_ld, accumulate);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+}  // extern "C"

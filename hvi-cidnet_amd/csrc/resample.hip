@@ -1,0 +1,191 @@
+// Bilinear resampling (align_corners=True, nn.UpsamplingBilinear2d) and PReLU pieces of
+// NormDownsample / NormUpsample (net/transformer_utils.py:38-43, 62-70):
+//   down_prelu_fwd : pre = bilinear(t -> floor(H/2) x floor(W/2)),  out = PReLU(pre)
+//   prelu_bwd      : d_pre = d_out * (pre > 0 ? 1 : a),  d_a = sum d_out * min-side(pre)
+//   bilinear_bwd   : adjoint of the bilinear map in GATHER form (no atomics, bitwise reproducible):
+//                    every input pixel sums the output pixels whose 2x2 footprint contains it.
+// All HBM-bound elementwise / small-stencil kernels: lanes run along x for coalesced rows.
+#include "common.h"
+
+namespace cidnet {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+struct Tap1 {
+  int i0, i1;
+  float l1;   // weight of i1; weight of i0 is 1 - l1
+};
+
+__device__ __forceinline__ Tap1 src_tap(int o, float scale, int in) {
+  const float f = scale * (float)o;
+  Tap1 t;
+  t.i0 = (int)f;
+  t.l1 = fminf(fmaxf(f - (float)t.i0, 0.f), 1.f);
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  return t;
+}
+
+__global__ __launch_bounds__(kThreads) void down_prelu_kernel(const float* __restrict__ t, const float* __restrict__ slope,
+                                                              float* __restrict__ pre, float* __restrict__ out, long planes,
+                                                              int H, int W, int h, int w) {
+  const long total = planes * h * w;
+  const float a = slope[0];
+  const float sh = ac_scale(H, h), sw = ac_scale(W, w);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const long pl = i / ((long)w * h);
+    const Tap1 ty = src_tap(y, sh, H), tx = src_tap(x, sw, W);
+    const float* p = t + pl * (long)H * W;
+    const float top = (1.f - tx.l1) * p[(long)ty.i0 * W + tx.i0] + tx.l1 * p[(long)ty.i0 * W + tx.i1];
+    const float bot = (1.f - tx.l1) * p[(long)ty.i1 * W + tx.i0] + tx.l1 * p[(long)ty.i1 * W + tx.i1];
+    const float v = (1.f - ty.l1) * top + ty.l1 * bot;
+    if (pre) pre[i] = v;
+    out[i] = v > 0.f ? v : a * v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void prelu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre,
+                                                             const float* __restrict__ slope, float* __restrict__ dpre,
+                                                             float* __restrict__ part, long n) {
+  __shared__ float red[kThreads / 64];
+  const float a = slope[0];
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g = load4u(dout + 4 * i), p = load4u(pre + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = p[e] > 0.f ? g[e] : a * g[e];
+      acc += p[e] > 0.f ? 0.f : g[e] * p[e];
+    }
+    store4u(dpre + 4 * i, o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float g = dout[i], p = pre[i];
+    dpre[i] = p > 0.f ? g : a * g;
+    acc += p > 0.f ? 0.f : g * p;
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void sum_parts_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) a += part[i];
+  const float s = block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// din[pl][yi][xi] = sum over (yo, xo) of wy * wx * dout[pl][yo][xo]
+__global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                long planes, int Hi, int Wi, int Ho, int Wo) {
+  const long total = planes * Hi * Wi;
+  const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+  const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xi = (int)(i % Wi);
+    const int yi = (int)((i / Wi) % Hi);
+    const long pl = i / ((long)Wi * Hi);
+    // candidate outputs: scale*o in [i-1, i+1)  (exact membership is re-tested with the forward's arithmetic)
+    int ylo = sh > 0.f ? (int)floorf((float)(yi - 1) * ish) - 1 : 0;
+    int yhi = sh > 0.f ? (int)ceilf((float)(yi + 1) * ish) + 1 : Ho - 1;
+    int xlo = sw > 0.f ? (int)floorf((float)(xi - 1) * isw) - 1 : 0;
+    int xhi = sw > 0.f ? (int)ceilf((float)(xi + 1) * isw) + 1 : Wo - 1;
+    ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, Ho - 1); xhi = min(xhi, Wo - 1);
+    const float* g = dout + pl * (long)Ho * Wo;
+    float s = 0.f;
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      const Tap1 ty = src_tap(yo, sh, Hi);
+      float wy = 0.f;
+      if (ty.i0 == yi) wy += 1.f - ty.l1;
+      if (ty.i1 == yi) wy += ty.l1;
+      if (wy == 0.f) continue;
+      float rs = 0.f;
+      for (int xo = xlo; xo <= xhi; ++xo) {
+        const Tap1 tx = src_tap(xo, sw, Wi);
+        float wx = 0.f;
+        if (tx.i0 == xi) wx += 1.f - tx.l1;
+        if (tx.i1 == xi) wx += tx.l1;
+        if (wx != 0.f) rs += wx * g[(long)yo * Wo + xo];
+      }
+      s += wy * rs;
+    }
+    din[i] = s;
+  }
+}
+
+// y = a + b (residual sums that no GEMM epilogue absorbs)
+__global__ __launch_bounds__(kThreads) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ y, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    store4u(y + 4 * i, load4u(a + 4 * i) + load4u(b + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    y[i] = a[i] + b[i];
+  }
+}
+
+inline int grid_for(long n, int cap = 4096) {
+  long g = (n + kThreads - 1) / kThreads;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+constexpr int kPreluBlocks = 1024;
+
+}  // namespace
+}  // namespace cidnet
+
+using namespace cidnet;
+
+extern "C" {
+
+int cidnet_down_prelu_fwd(const float* t, const float* slope, float* pre, float* out, int B, int C, int H, int W,
+                          void* stream) {
+  CIDNET_CHECK_ARG(t && slope && out && B > 0 && C > 0 && H > 1 && W > 1);
+  const int h = H / 2, w = W / 2;
+  const long planes = (long)B * C;
+  hipLaunchKernelGGL(down_prelu_kernel, dim3(grid_for(planes * h * w)), dim3(kThreads), 0, (hipStream_t)stream, t, slope, pre,
+                     out, planes, H, W, h, w);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+long cidnet_prelu_bwd_ws_floats(void) { return kPreluBlocks; }
+
+int cidnet_prelu_bwd(const float* dout, const float* pre, const float* slope, float* dpre, float* dslope, float* ws,
+                     long ws_floats, long n, void* stream) {
+  CIDNET_CHECK_ARG(dout && pre && slope && dpre && dslope && ws && n > 0);
+  if (ws_floats < kPreluBlocks) return CIDNET_ERR_WS;
+  const int grid = grid_for((n + 3) / 4, kPreluBlocks);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, dout, pre, slope, dpre, ws, n);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, grid, dslope);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_bilinear_bwd(const float* dout, float* din, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  CIDNET_CHECK_ARG(dout && din && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  const long planes = (long)B * C;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(planes * Hi * Wi, 16384)), dim3(kThreads), 0, (hipStream_t)stream,
+                     dout, din, planes, Hi, Wi, Ho, Wo);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_add(const float* a, const float* b, float* y, long n, void* stream) {
+  CIDNET_CHECK_ARG(a && b && y && n > 0);
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, a, b, y, n);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+}  // extern "C"

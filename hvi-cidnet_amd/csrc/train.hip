@@ -1,0 +1,96 @@
+// Training-step pieces around the network (reference: train.py:56-73): the L1 loss
+// mean(|out - gt|) with its gradient in one pass, and a fused Adam update over one flat parameter
+// buffer (torch.optim.Adam semantics, train.py:166) so the 191 parameter tensors cost one launch.
+#include "common.h"
+
+namespace cidnet {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kBlocks = 1024;
+
+__global__ __launch_bounds__(kThreads) void l1_kernel(const float* __restrict__ out, const float* __restrict__ gt,
+                                                      float* __restrict__ grad, float* __restrict__ part, long n, float inv_n) {
+  __shared__ float red[kThreads / 64];
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 d = load4u(out + 4 * i) - load4u(gt + 4 * i);
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc += fabsf(d[e]);
+      g[e] = d[e] > 0.f ? inv_n : (d[e] < 0.f ? -inv_n : 0.f);
+    }
+    if (grad) store4u(grad + 4 * i, g);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float d = out[i] - gt[i];
+    acc += fabsf(d);
+    if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void l1_finish_kernel(const float* __restrict__ part, int n, float inv_n, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) a += part[i];
+  const float s = block_sum(a, red);
+  if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                        float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+}  // namespace cidnet
+
+using namespace cidnet;
+
+extern "C" {
+
+long cidnet_l1_loss_ws_floats(void) { return kBlocks; }
+
+int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, float* ws, long ws_floats, long n,
+                   void* stream) {
+  CIDNET_CHECK_ARG(out && gt && loss && ws && n > 0);
+  if (ws_floats < kBlocks) return CIDNET_ERR_WS;
+  long g = ((n + 3) / 4 + kThreads - 1) / kThreads;
+  const int grid = (int)(g > kBlocks ? kBlocks : (g < 1 ? 1 : g));
+  const float inv_n = 1.0f / (float)n;
+  hipLaunchKernelGGL(l1_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, out, gt, grad, ws, n, inv_n);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, grid, inv_n, loss);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float grad_scale, void* stream) {
+  CIDNET_CHECK_ARG(p && g && m && v && n > 0 && step > 0);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  long gsz = (n + kThreads - 1) / kThreads;
+  const int grid = (int)(gsz > 4096 ? 4096 : gsz);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2_sqrt, grad_scale);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+}  // extern "C"

@@ -133,3 +133,447 @@ def phvit_sextant(hvi, k):
     lib().call("cidnet_phvit_fwd", None, None, _p(hvi), None, _f(k), 0, _f(1.3), 0, _f(1.0), _p(out), _p(sx), B, H, W,
                _stream())
     return sx
+
+
+# --------------------------------------------------------------------------------------------
+# shared plumbing for the conv / attention ops
+# --------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _ws(n_floats, device):
+    """Stream-ordered scratch buffer (grown on demand, reused by consecutive launches)."""
+    key = (device.type, device.index)
+    t = _WS.get(key)
+    if t is None or t.numel() < n_floats:
+        t = torch.empty(max(int(n_floats), 1 << 20), device=device, dtype=torch.float32)
+        _WS[key] = t
+    return t
+
+
+def _po(t, off_floats=0):
+    return _vp(t.data_ptr() + 4 * int(off_floats))
+
+
+def _raw(name, *a):
+    return lib().raw(name)(*a)
+
+
+def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
+    lib().call("cidnet_pw_conv", _po(x, x_off), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _po(y, y_off), y_bs,
+               _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, _stream())
+
+
+def pw_wgrad(dy, dy_off, dy_bs, x, x_off, x_bs, dw, dw_off, dw_ld, B, M, N, HW, per_sample=False):
+    n = _raw("cidnet_pw_wgrad_ws_floats", B, M, N, HW)
+    ws = _ws(n, dy.device)
+    lib().call("cidnet_pw_wgrad", _po(dy, dy_off), dy_bs, _po(x, x_off), x_bs, _po(dw, dw_off), dw_ld, int(per_sample), 0,
+               _p(ws), ws.numel(), B, M, N, HW, _stream())
+
+
+def dw3x3(inp, w1, w2, csplit, out, B, C, H, W, flip=False, addend=None):
+    lib().call("cidnet_dw3x3", _p(inp), _p(w1), _p(w2), csplit, _p(addend), _p(out), int(flip), B, C, H, W, _stream())
+
+
+def dw3x3_wgrad(inp, gout, gw1, gw2, csplit, B, C, H, W):
+    n = _raw("cidnet_dw3x3_wgrad_ws_floats", B, C, H, W)
+    ws = _ws(n, inp.device)
+    lib().call("cidnet_dw3x3_wgrad", _p(inp), _p(gout), _p(gw1), _p(gw2), csplit, _p(ws), ws.numel(), B, C, H, W, _stream())
+
+
+def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False):
+    lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
+               H, W, _stream())
+
+
+def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False):
+    n = _raw("cidnet_conv3x3_wgrad_ws_floats", B, M, N, H, W)
+    ws = _ws(n, dy.device)
+    lib().call("cidnet_conv3x3_wgrad", _p(dy), M * H * W, _p(x), N * H * W, int(replicate), _p(dw), _p(ws), ws.numel(), B, M,
+               N, H, W, _stream())
+
+
+def prelu_bwd(go, pre, slope):
+    dpre = torch.empty_like(pre)
+    dslope = grad_like(slope)
+    n = _raw("cidnet_prelu_bwd_ws_floats")
+    ws = _ws(n, go.device)
+    lib().call("cidnet_prelu_bwd", _p(go), _p(pre), _p(slope), _p(dpre), _p(dslope), _p(ws), ws.numel(), go.numel(), _stream())
+    return dpre, dslope
+
+
+# --------------------------------------------------------------------------------------------
+# K3: LayerNorm (channels first)
+# --------------------------------------------------------------------------------------------
+class LayerNormCFFn(torch.autograd.Function):
+    """Reference: LayerNorm.forward (channels_first), net/transformer_utils.py:24-29."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _check(x, weight, bias)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib().call("cidnet_ln_cf_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = _c(gy)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = grad_like(weight)
+        gb = torch.empty_like(weight)
+        n = _raw("cidnet_ln_cf_bwd_ws_floats", C)
+        ws = _ws(n, x.device)
+        lib().call("cidnet_ln_cf_bwd", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), _p(gx), _p(gw), _p(gb), _p(ws), ws.numel(),
+                   B, C, H * W, _stream())
+        return gx, gw, gb, None
+
+
+# --------------------------------------------------------------------------------------------
+# K6/K7: cross-attention block with the residual:  out = x_res + CAB(xn, yn)
+# --------------------------------------------------------------------------------------------
+class CABResidualFn(torch.autograd.Function):
+    """Reference: CAB.forward (net/LCA.py:19-41) plus the residual add of LCA.py:79 / :91."""
+
+    @staticmethod
+    def forward(ctx, x_res, xn, yn, temperature, wq, wq_dw, wkv, wkv_dw, wp, heads):
+        _check(x_res, xn, yn, temperature, wq, wq_dw, wkv, wkv_dw, wp)
+        x_res, xn, yn = _c(x_res), _c(xn), _c(yn)
+        B, C, H, W = xn.shape
+        HW = H * W
+        dev = xn.device
+        ch = C // heads
+        qkv0 = torch.empty((B, 3 * C, H, W), device=dev, dtype=torch.float32)
+        pw_conv(xn, 0, C * HW, wq, 0, 0, C, 1, qkv0, 0, 3 * C * HW, B, C, C, HW)
+        pw_conv(yn, 0, C * HW, wkv, 0, 0, C, 1, qkv0, C * HW, 3 * C * HW, B, 2 * C, C, HW)
+        qkv = torch.empty_like(qkv0)
+        dw3x3(qkv0, wq_dw, wkv_dw, C, qkv, B, 3 * C, H, W)
+        attn = torch.empty((B, heads, ch, ch), device=dev, dtype=torch.float32)
+        shat = torch.empty_like(attn)
+        nq = torch.empty((B, C), device=dev, dtype=torch.float32)
+        nk = torch.empty_like(nq)
+        M = torch.empty((B, C, C), device=dev, dtype=torch.float32)
+        n = _raw("cidnet_attn_gram_ws_floats", B, C, heads, HW)
+        ws = _ws(n, dev)
+        lib().call("cidnet_attn_fwd", _p(qkv), _p(temperature), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(M), _p(ws),
+                   ws.numel(), B, C, heads, HW, _stream())
+        out = torch.empty_like(x_res)
+        pw_conv(qkv, 2 * C * HW, 3 * C * HW, M, 0, C * C, C, 1, out, 0, C * HW, B, C, C, HW, res=x_res, r_bs=C * HW)
+        ctx.save_for_backward(xn, yn, qkv0, qkv, attn, shat, nq, nk, M, temperature, wq, wq_dw, wkv, wkv_dw, wp)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, yn, qkv0, qkv, attn, shat, nq, nk, M, temperature, wq, wq_dw, wkv, wkv_dw, wp = ctx.saved_tensors
+        heads = ctx.heads
+        B, C, H, W = xn.shape
+        HW = H * W
+        dev = xn.device
+        g = _c(g)
+        dqkv = torch.empty_like(qkv)
+        # dv = M^T g ; dM = g v^T
+        pw_conv(g, 0, C * HW, M, 0, C * C, 1, C, dqkv, 2 * C * HW, 3 * C * HW, B, C, C, HW)
+        dM = torch.empty_like(M)
+        pw_wgrad(g, 0, C * HW, qkv, 2 * C * HW, 3 * C * HW, dM, 0, C, B, C, C, HW, per_sample=True)
+        dwp_b = torch.empty_like(M)
+        dT_b = torch.empty((B, heads), device=dev, dtype=torch.float32)
+        wqk = torch.empty((B, 2 * C, 2 * C), device=dev, dtype=torch.float32)
+        lib().call("cidnet_attn_bwd", _p(dM), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(temperature), _p(dwp_b), _p(dT_b),
+                   _p(wqk), B, C, heads, _stream())
+        g_wp = grad_like(wp)
+        lib().call("cidnet_sum_rows", _p(dwp_b), B, C * C, _p(g_wp), _stream())
+        g_T = grad_like(temperature)
+        lib().call("cidnet_sum_rows", _p(dT_b), B, heads, _p(g_T), _stream())
+        # [dq;dk] = Wqk_b [q;k]
+        pw_conv(qkv, 0, 3 * C * HW, wqk, 0, 4 * C * C, 2 * C, 1, dqkv, 0, 3 * C * HW, B, 2 * C, 2 * C, HW)
+        # depthwise backward
+        g_wq_dw = grad_like(wq_dw)
+        g_wkv_dw = grad_like(wkv_dw)
+        dw3x3_wgrad(qkv0, dqkv, g_wq_dw, g_wkv_dw, C, B, 3 * C, H, W)
+        dqkv0 = torch.empty_like(qkv0)
+        dw3x3(dqkv, wq_dw, wkv_dw, C, dqkv0, B, 3 * C, H, W, flip=True)
+        # pointwise backward
+        g_wq = grad_like(wq)
+        g_wkv = grad_like(wkv)
+        pw_wgrad(dqkv0, 0, 3 * C * HW, xn, 0, C * HW, g_wq, 0, C, B, C, C, HW)
+        pw_wgrad(dqkv0, C * HW, 3 * C * HW, yn, 0, C * HW, g_wkv, 0, C, B, 2 * C, C, HW)
+        dxn = dyn = None
+        if ctx.needs_input_grad[1]:
+            dxn = torch.empty_like(xn)
+            pw_conv(dqkv0, 0, 3 * C * HW, wq, 0, 0, 1, C, dxn, 0, C * HW, B, C, C, HW)
+        if ctx.needs_input_grad[2]:
+            dyn = torch.empty_like(yn)
+            pw_conv(dqkv0, C * HW, 3 * C * HW, wkv, 0, 0, 1, C, dyn, 0, C * HW, B, C, 2 * C, HW)
+        return g, dxn, dyn, g_T, g_wq, g_wq_dw, g_wkv, g_wkv_dw, g_wp, None
+
+
+# --------------------------------------------------------------------------------------------
+# K8: IEL gated FFN:  out = [res +] Wout * gate(dw(Win * xn))
+# --------------------------------------------------------------------------------------------
+class IELFn(torch.autograd.Function):
+    """Reference: IEL.forward (net/LCA.py:60-67); `res` is the residual of I_LCA (LCA.py:92)."""
+
+    @staticmethod
+    def forward(ctx, xn, res, w_in, w_dw, w_dw1, w_dw2, w_out):
+        _check(xn, res, w_in, w_dw, w_dw1, w_dw2, w_out)
+        xn = _c(xn)
+        res = _c(res) if res is not None else None
+        B, C, H, W = xn.shape
+        HW = H * W
+        h = w_dw1.shape[0]
+        dev = xn.device
+        pin = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32)
+        pw_conv(xn, 0, C * HW, w_in, 0, 0, C, 1, pin, 0, 2 * h * HW, B, 2 * h, C, HW)
+        u = torch.empty_like(pin)
+        dw3x3(pin, w_dw, None, 2 * h, u, B, 2 * h, H, W)
+        gate = torch.empty((B, h, H, W), device=dev, dtype=torch.float32)
+        lib().call("cidnet_iel_gate_fwd", _p(u), _p(w_dw1), _p(w_dw2), _p(gate), B, h, H, W, _stream())
+        out = torch.empty_like(xn)
+        pw_conv(gate, 0, h * HW, w_out, 0, 0, h, 1, out, 0, C * HW, B, C, h, HW, res=res, r_bs=C * HW)
+        ctx.save_for_backward(xn, pin, u, gate, w_in, w_dw, w_dw1, w_dw2, w_out)
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        xn, pin, u, gate, w_in, w_dw, w_dw1, w_dw2, w_out = ctx.saved_tensors
+        B, C, H, W = xn.shape
+        HW = H * W
+        h = w_dw1.shape[0]
+        go = _c(go)
+        g_wout = grad_like(w_out)
+        pw_wgrad(go, 0, C * HW, gate, 0, h * HW, g_wout, 0, h, B, C, h, HW)
+        dg = torch.empty_like(gate)
+        pw_conv(go, 0, C * HW, w_out, 0, 0, 1, h, dg, 0, h * HW, B, h, C, HW)
+        da = torch.empty_like(u)
+        ds = torch.empty_like(u)
+        lib().call("cidnet_iel_gate_bwd", _p(u), _p(w_dw1), _p(w_dw2), _p(dg), _p(da), _p(ds), B, h, H, W, _stream())
+        g_dw1 = grad_like(w_dw1)
+        g_dw2 = grad_like(w_dw2)
+        dw3x3_wgrad(u, da, g_dw1, g_dw2, h, B, 2 * h, H, W)
+        du = ds                                         # du = ds + dw^T(da), written in place over ds
+        dw3x3(da, w_dw1, w_dw2, h, du, B, 2 * h, H, W, flip=True, addend=ds)
+        g_dw = grad_like(w_dw)
+        dw3x3_wgrad(pin, du, g_dw, None, 2 * h, B, 2 * h, H, W)
+        dpin = da                                       # reuse
+        dw3x3(du, w_dw, None, 2 * h, dpin, B, 2 * h, H, W, flip=True)
+        g_win = grad_like(w_in)
+        pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW)
+        dxn = None
+        if ctx.needs_input_grad[0]:
+            dxn = torch.empty_like(xn)
+            pw_conv(dpin, 0, 2 * h * HW, w_in, 0, 0, 1, C, dxn, 0, C * HW, B, C, 2 * h, HW)
+        return dxn, (go if ctx.has_res else None), g_win, g_dw, g_dw1, g_dw2, g_wout
+
+
+# --------------------------------------------------------------------------------------------
+# K9/K10/K11: down / up blocks and the replicate-pad stem / head convs
+# --------------------------------------------------------------------------------------------
+class DownFn(torch.autograd.Function):
+    """Reference: NormDownsample.forward, net/transformer_utils.py:38-43: conv3x3 -> bilinear x0.5
+    (align_corners=True) -> PReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, slope):
+        _check(x, w, slope)
+        x = _c(x)
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        t = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
+        conv3x3(x, w, t, B, Co, Ci, H, W, 9 * Ci, 9)
+        pre = torch.empty((B, Co, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        out = torch.empty_like(pre)
+        lib().call("cidnet_down_prelu_fwd", _p(t), _p(slope), _p(pre), _p(out), B, Co, H, W, _stream())
+        ctx.save_for_backward(x, w, slope, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w, slope, pre = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        go = _c(go)
+        dpre, dslope = prelu_bwd(go, pre, slope)
+        dt = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
+        lib().call("cidnet_bilinear_bwd", _p(dpre), _p(dt), B, Co, H, W, H // 2, W // 2, _stream())
+        gw = grad_like(w)
+        conv3x3_wgrad(dt, x, gw, B, Co, Ci, H, W)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv3x3(dt, w, dx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True)
+        return dx, gw, dslope
+
+
+class UpFn(torch.autograd.Function):
+    """Reference: NormUpsample.forward, net/transformer_utils.py:62-70: conv3x3 -> bilinear x2 ->
+    cat(skip) -> conv1x1 -> PReLU.  The 1x1 conv is split over the concat and its up-sampled half is
+    applied BEFORE the (linear) bilinear map, at a quarter of the pixels; no concat is materialised."""
+
+    @staticmethod
+    def forward(ctx, x, skip, w, w_up, slope):
+        _check(x, skip, w, w_up, slope)
+        x, skip = _c(x), _c(skip)
+        B, Ci, h, wd = x.shape
+        Co = w.shape[0]
+        if skip.shape != (B, Co, 2 * h, 2 * wd):
+            raise RuntimeError(f"NormUpsample: skip {tuple(skip.shape)} does not match upsampled {(B, Co, 2 * h, 2 * wd)}")
+        dev = x.device
+        t = torch.empty((B, Co, h, wd), device=dev, dtype=torch.float32)
+        conv3x3(x, w, t, B, Co, Ci, h, wd, 9 * Ci, 9)
+        z = torch.empty_like(t)
+        pw_conv(t, 0, Co * h * wd, w_up, 0, 0, 2 * Co, 1, z, 0, Co * h * wd, B, Co, Co, h * wd)
+        out = torch.empty_like(skip)
+        pre = torch.empty_like(skip)
+        lib().call("cidnet_pw_conv_up_prelu", _p(skip), Co * 4 * h * wd, _po(w_up, Co), 2 * Co, 1, _p(z), _p(slope), _p(out),
+                   _p(pre), B, Co, Co, h, wd, _stream())
+        ctx.save_for_backward(x, skip, w, w_up, slope, t, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, skip, w, w_up, slope, t, pre = ctx.saved_tensors
+        B, Ci, h, wd = x.shape
+        Co = w.shape[0]
+        HWl, HWh = h * wd, 4 * h * wd
+        go = _c(go)
+        dpre, dslope = prelu_bwd(go, pre, slope)
+        g_wup = grad_like(w_up)
+        pw_wgrad(dpre, 0, Co * HWh, skip, 0, Co * HWh, g_wup, Co, 2 * Co, B, Co, Co, HWh)
+        dskip = None
+        if ctx.needs_input_grad[1]:
+            dskip = torch.empty_like(skip)
+            pw_conv(dpre, 0, Co * HWh, w_up, Co, 0, 1, 2 * Co, dskip, 0, Co * HWh, B, Co, Co, HWh)
+        dz = torch.empty_like(t)
+        lib().call("cidnet_bilinear_bwd", _p(dpre), _p(dz), B, Co, h, wd, 2 * h, 2 * wd, _stream())
+        pw_wgrad(dz, 0, Co * HWl, t, 0, Co * HWl, g_wup, 0, 2 * Co, B, Co, Co, HWl)
+        dt = torch.empty_like(t)
+        pw_conv(dz, 0, Co * HWl, w_up, 0, 0, 1, 2 * Co, dt, 0, Co * HWl, B, Co, Co, HWl)
+        gw = grad_like(w)
+        conv3x3_wgrad(dt, x, gw, B, Co, Ci, h, wd)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv3x3(dt, w, dx, B, Ci, Co, h, wd, 9, 9 * Ci, flip=True)
+        return dx, dskip, gw, g_wup, dslope
+
+
+class RepConv3x3Fn(torch.autograd.Function):
+    """Reference: nn.ReplicationPad2d(1) + valid 3x3 conv (net/CIDNet.py:21-24,32-35,39-42,50-53)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _check(x, w)
+        x = _c(x)
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        y = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
+        conv3x3(x, w, y, B, Co, Ci, H, W, 9 * Ci, 9, replicate=True)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        go = _c(go)
+        gw = grad_like(w)
+        conv3x3_wgrad(go, x, gw, B, Co, Ci, H, W, replicate=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv3x3(go, w, dx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True)
+            lib().call("cidnet_conv3x3_replicate_dgrad_fix", _p(go), _p(w), _p(dx), B, Co, Ci, H, W, _stream())
+        return dx, gw
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _check(a, b)
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        lib().call("cidnet_add", _p(a), _p(b), _p(y), a.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+# --------------------------------------------------------------------------------------------
+# training-step pieces: L1 loss (loss + gradient in one pass) and fused flat Adam
+# --------------------------------------------------------------------------------------------
+class L1LossFn(torch.autograd.Function):
+    """mean(|out - gt|): reference L1Loss (loss/losses.py:10-20, loss_utils.py l1_loss, reduction='mean')."""
+
+    @staticmethod
+    def forward(ctx, out, gt):
+        _check(out, gt)
+        out, gt = _c(out), _c(gt)
+        grad = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        loss = torch.empty((), device=out.device, dtype=torch.float32)
+        n = _raw("cidnet_l1_loss_ws_floats")
+        ws = _ws(n, out.device)
+        lib().call("cidnet_l1_loss", _p(out), _p(gt), _p(grad), _p(loss), _p(ws), ws.numel(), out.numel(), _stream())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None        # g is the scalar d(total)/d(loss); 1.0 in the benchmark step
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _check(p, g, m, v)
+    lib().call("cidnet_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _f(lr), _f(beta1), _f(beta2), _f(eps),
+               _f(weight_decay), int(step), _f(grad_scale), _stream())
+
+
+# --------------------------------------------------------------------------------------------
+# gradient arena: weight gradients are written straight into one flat buffer (the all-reduce /
+# optimizer operand) instead of 191 separately allocated tensors
+# --------------------------------------------------------------------------------------------
+_ARENA = None
+
+
+def set_grad_arena(flat_p, flat_g, exclude_ptrs=()):
+    """Parameters must be views into `flat_p`; their gradients are then produced as the matching
+    views of `flat_g`.  `exclude_ptrs`: data_ptr()s of parameters used more than once per step
+    (their gradients must be accumulated by autograd instead)."""
+    global _ARENA
+    _ARENA = None if flat_p is None else (flat_p.data_ptr(), flat_p.numel(), flat_g, frozenset(exclude_ptrs))
+
+
+_GL_COUNT = None      # {data_ptr: number of grad_like() calls}: probe for parameters used more than once
+
+
+def start_grad_probe():
+    global _GL_COUNT
+    _GL_COUNT = {}
+
+
+def stop_grad_probe():
+    global _GL_COUNT
+    c, _GL_COUNT = _GL_COUNT, None
+    return c or {}
+
+
+def grad_like(w):
+    if _GL_COUNT is not None:
+        _GL_COUNT[w.data_ptr()] = _GL_COUNT.get(w.data_ptr(), 0) + 1
+    if _ARENA is not None:
+        base, n, flat_g, excl = _ARENA
+        off = (w.data_ptr() - base) // 4
+        if 0 <= off < n and w.data_ptr() not in excl and w.is_contiguous():
+            return flat_g[off:off + w.numel()].view(w.shape)
+    return torch.empty_like(w)

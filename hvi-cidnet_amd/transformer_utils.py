@@ -1,0 +1,69 @@
+"""Drop-ins for the reference's net/transformer_utils.py (LayerNorm, NormDownsample, NormUpsample):
+same constructor arguments, sub-module tree and state_dict keys; forward runs the HIP ops."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class LayerNorm(nn.Module):
+    """Reference: net/transformer_utils.py:5-29.  Only `channels_first` is on the CIDNet hot path;
+    `channels_last` (never used by the reference models) is rejected rather than routed to ATen."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_first"):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.data_format = data_format
+        if self.data_format not in ["channels_last", "channels_first"]:
+            raise NotImplementedError
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        if self.data_format != "channels_first":
+            raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
+        return ops.LayerNormCFFn.apply(x, self.weight, self.bias, self.eps)
+
+
+class NormDownsample(nn.Module):
+    """Reference: net/transformer_utils.py:31-48.  `down` keeps the reference's Sequential(Conv2d,
+    UpsamplingBilinear2d) as the parameter container (key `down.0.weight`); the fused HIP path
+    conv3x3 -> bilinear(align_corners) -> PReLU replaces calling it."""
+
+    def __init__(self, in_ch, out_ch, scale=0.5, use_norm=False):
+        super().__init__()
+        if scale != 0.5:
+            raise NotImplementedError("NormDownsample: only scale=0.5 (the CIDNet configuration) is implemented")
+        self.use_norm = use_norm
+        if self.use_norm:
+            self.norm = LayerNorm(out_ch)
+        self.prelu = nn.PReLU()
+        self.down = nn.Sequential(
+            nn.Conv2d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=False),
+            nn.UpsamplingBilinear2d(scale_factor=scale))
+
+    def forward(self, x):
+        x = ops.DownFn.apply(x, self.down[0].weight, self.prelu.weight)
+        return self.norm(x) if self.use_norm else x
+
+
+class NormUpsample(nn.Module):
+    """Reference: net/transformer_utils.py:50-70."""
+
+    def __init__(self, in_ch, out_ch, scale=2, use_norm=False):
+        super().__init__()
+        if scale != 2:
+            raise NotImplementedError("NormUpsample: only scale=2 (the CIDNet configuration) is implemented")
+        self.use_norm = use_norm
+        if self.use_norm:
+            self.norm = LayerNorm(out_ch)
+        self.prelu = nn.PReLU()
+        self.up_scale = nn.Sequential(
+            nn.Conv2d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=False),
+            nn.UpsamplingBilinear2d(scale_factor=scale))
+        self.up = nn.Conv2d(out_ch * 2, out_ch, kernel_size=1, stride=1, padding=0, bias=False)
+
+    def forward(self, x, y):
+        x = ops.UpFn.apply(x, y, self.up_scale[0].weight, self.up.weight, self.prelu.weight)
+        return self.norm(x) if self.use_norm else x

@@ -61,6 +61,105 @@ int cidnet_phvit_bwd(const float* hv, const float* iv, const float* hvi, const f
                      const float* g_rgb, float* g_hvi, float* g_hv, float* g_iv, int B, int H, int W,
                      void* stream);
 
+/* ---- K3: channels-first LayerNorm  (LayerNorm.forward, net/transformer_utils.py:24-29) ---------
+ * x,y: (B,C,HW).  mean/rstd (B,HW each, optional pair) are saved for the backward. */
+int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                     float* rstd, int B, int C, long HW, float eps, void* stream);
+long cidnet_ln_cf_bwd_ws_floats(int C);
+/* gx optional (NULL: parameter gradients only); gw, gb: (C) each, overwritten. */
+int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean,
+                     const float* rstd, float* gx, float* gw, float* gb, float* ws, long ws_floats,
+                     int B, int C, long HW, void* stream);
+
+/* ---- K4: pointwise (1x1) convolution on the fp32 MFMA -----------------------------------------
+ * (nn.Conv2d(k=1): net/LCA.py:13,15,17,51,57; net/transformer_utils.py:60)
+ * Per sample b:  Y[b] (M x HW) = A_b (M x K) * X[b] (K x HW)  [+ R[b]],
+ *   A_b[m][k] = Wt[b*w_bs + m*w_ms + k*w_ks]   (w_bs = 0: shared weights; forward: w_ms=K,w_ks=1;
+ *   data gradient: w_ms=1, w_ks=<Cin>), X[b] at X + b*x_bs with channel stride HW (same for Y, R),
+ *   so channel slices of wider tensors can be read / written in place.  R may alias Y. */
+int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
+                   float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
+                   void* stream);
+/* NormUpsample tail (net/transformer_utils.py:64-66): pre = Wt*X + bilinear_x2(Z), Y = PReLU(pre).
+ * Z: (B,M,zh,zw) low-resolution, X: skip tensor (B,K,2zh,2zw), Y/Ypre: (B,M,2zh,2zw). */
+int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks,
+                            const float* Z, const float* slope, float* Y, float* Ypre, int B, int M,
+                            int K, int zh, int zw, void* stream);
+/* Weight gradient dW[m][n] = sum_{b,p} dY[b][m][p] X[b][n][p]; per_sample: dW is (B,M,N) without
+ * the batch sum.  dw_ld = row stride of dW (>= N).  Fixed-order reduction (reproducible). */
+long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW);
+int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld,
+                    int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N,
+                    long HW, void* stream);
+
+/* ---- K5 / K8: depthwise 3x3 (zero pad) and the IEL gate  (net/LCA.py:14,16,53-55,62-65) --------
+ * out = dw3x3(in) [+ addend]; channel c uses w1[c] if c < csplit else w2[c-csplit] (weights (.,1,3,3));
+ * flip != 0 applies the 180-degree rotated taps (= data gradient of the forward). */
+int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend,
+                 float* out, int flip, int B, int C, int H, int W, void* stream);
+long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W);
+int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw2, int csplit,
+                       float* ws, long ws_floats, int B, int C, int H, int W, void* stream);
+/* g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2);  u: (B,2h,H,W) = [u1;u2], g: (B,h,H,W). */
+int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h,
+                        int H, int W, void* stream);
+/* da = d(dw1/2 output), ds = d(s1/s2) both (B,2h,H,W); du = ds + dw3x3(da, flipped) by the caller. */
+int cidnet_iel_gate_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* da,
+                        float* ds, int B, int h, int H, int W, void* stream);
+
+/* ---- K9/K10/K11: dense 3x3 convolution, pad 1, fp32 MFMA implicit GEMM -------------------------
+ * (net/transformer_utils.py:39,58 zero pad; net/CIDNet.py:21-24,32-35,39-42,50-53 replicate pad)
+ * Y[b][m] = sum_{k,tap} Wt[m*w_ms + k*w_ks + tap'] * Xpad[b][k] ; forward: w_ms=9K, w_ks=9, flip=0;
+ * data gradient of the zero-pad conv: X=dY, M=Cin, K=Cout, w_ms=9, w_ks=9*Cin, flip=1. */
+int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
+                   int replicate, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
+long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W);
+int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int replicate,
+                         float* dW, float* ws, long ws_floats, int B, int M, int N, int H, int W,
+                         void* stream);
+/* Adds to gX (computed by the zero-pad data gradient) the taps that read replicated border pixels. */
+int cidnet_conv3x3_replicate_dgrad_fix(const float* gY, const float* Wt, float* gX, int B, int Co,
+                                       int Ci, int H, int W, void* stream);
+
+/* ---- resampling / PReLU pieces of NormDownsample, NormUpsample ---------------------------------
+ * (nn.UpsamplingBilinear2d == bilinear, align_corners=True; nn.PReLU with one slope) */
+int cidnet_down_prelu_fwd(const float* t, const float* slope, float* pre, float* out, int B, int C,
+                          int H, int W, void* stream);
+long cidnet_prelu_bwd_ws_floats(void);
+int cidnet_prelu_bwd(const float* dout, const float* pre, const float* slope, float* dpre,
+                     float* dslope, float* ws, long ws_floats, long n, void* stream);
+/* adjoint of bilinear (Hi,Wi)->(Ho,Wo): din (B,C,Hi,Wi) from dout (B,C,Ho,Wo), gather form. */
+int cidnet_bilinear_bwd(const float* dout, float* din, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                        void* stream);
+int cidnet_add(const float* a, const float* b, float* y, long n, void* stream);
+
+/* ---- K7: channel attention of CAB  (net/LCA.py:26-38) -------------------------------------------
+ * qkv: (B,3C,HW) = [q;k;v] after the depthwise convs.  Produces attn = softmax(normalize(q)
+ * normalize(k)^T * temperature) per (b,head), the normalised logits shat, the row norms nq,nk (B,C)
+ * and M[b] = Wp * blockdiag(attn[b]) (B,C,C) so that project_out(attn @ v) = M[b] * v[b]. */
+long cidnet_attn_gram_ws_floats(int B, int C, int heads, long HW);
+int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp, float* attn,
+                    float* shat, float* nq, float* nk, float* M, float* ws, long ws_floats, int B,
+                    int C, int heads, long HW, void* stream);
+/* From dM (B,C,C): per-sample dWp_b (B,C,C), dT_b (B,heads), and Wqk (B,2C,2C) with
+ * [dq;dk][b] = Wqk[b] * [q;k][b]  (softmax + L2-normalisation backward folded). */
+int cidnet_attn_bwd(const float* dM, const float* Wp, const float* attn, const float* shat,
+                    const float* nq, const float* nk, const float* temperature, float* dWp_b,
+                    float* dT_b, float* Wqk, int B, int C, int heads, void* stream);
+/* out[i] = sum_r in[r*n + i] (fixed order) */
+int cidnet_sum_rows(const float* in, int n_red, long n, float* out, void* stream);
+
+/* ---- training-step pieces (train.py:56-73) ------------------------------------------------------
+ * loss = mean(|out - gt|) (L1Loss, loss/losses.py:10-20) and grad = sign(out - gt)/n in one pass. */
+long cidnet_l1_loss_ws_floats(void);
+int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, float* ws,
+                   long ws_floats, long n, void* stream);
+/* torch.optim.Adam step (train.py:166) over one flat buffer; g is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce).  step = 1-based update count. */
+int cidnet_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

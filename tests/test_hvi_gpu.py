@@ -46,7 +46,14 @@ def test_hvit_golden(golden, dev, name, k):
     z = ops.PHVITFn.apply(z_in, None, None, kk.detach(), False, 1.3, False, 1.0)
     assert _maxdiff(z, g[f"phvit_rt_{tag}_out"]) <= 5e-6
     z.backward(_t(g[f"phvit_rt_{tag}_gout"], dev))
-    _grad_ok(z_in.grad, g[f"phvit_rt_{tag}_gin"])
+    # HSV->RGB is continuous but not differentiable across sextant boundaries, and quantised images
+    # sit exactly on them (hue = n/6): compare gradients where the sextant decision agrees
+    kf = float(np.float32(k))
+    hi = ops.phvit_sextant(z_in.detach(), kf).cpu()
+    same = (hi == O.phvit_sextant(_t(g[f"hvit_{tag}_out"]), kf)).unsqueeze(1).expand(-1, 3, -1, -1)
+    assert same.float().mean().item() > (0.85 if name == "adv" else 0.97)   # adv: 28 hand-picked boundary pixels
+    ga, gb = z_in.grad.detach().cpu(), _t(g[f"phvit_rt_{tag}_gin"])
+    assert (ga - gb).abs()[same].max().item() <= 1e-4 * gb.abs().max().item() + 1e-7
 
 
 @pytest.mark.parametrize("name", ["rand", "adv"])

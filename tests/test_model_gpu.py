@@ -1,0 +1,164 @@
+"""GPU parity of the reference-named blocks and of the whole CIDNet against the golden fixtures
+(the reference's own outputs and gradients, tests/golden/*.npz) through the public module API.
+Bars: outputs 1e-4 abs (north star; observed ~1e-6), gradients 1e-4 of the tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cidnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def out_ok(a, b, tol=1e-4, what=""):
+    d = (a.detach().cpu().double() - _t(b).double()).abs().max().item()
+    assert d <= tol, f"{what}: max abs diff {d:.3e}"
+    return d
+
+
+def grad_ok(a, b, rel=1e-4, what=""):
+    b = _t(b).double()
+    d = (a.detach().cpu().double() - b).abs().max().item()
+    tol = rel * b.abs().max().item() + 1e-7
+    assert d <= tol, f"{what}: max diff {d:.3e} > {tol:.3e}"
+
+
+def load(module, params, prefix=""):
+    sd = {k: params[prefix + k] for k in module.state_dict().keys()}
+    module.load_state_dict(sd, strict=True)
+
+
+CASES = [("w12", (12, 12, 24, 48)), ("w36", (36, 36, 72, 144))]
+
+
+@pytest.mark.parametrize("tag,chans", CASES)
+def test_layernorm_golden(golden, dev, tag, chans):
+    import hvi_cidnet_amd as P
+    g = golden("blocks")
+    p = O.make_params(11, channels=chans)
+    m = P.LayerNorm(chans[1])
+    load(m, p, "I_LCA1.norm.")
+    m.to(dev)
+    x = _t(g[f"ln_{tag}_x"], dev).requires_grad_(True)
+    y = m(x)
+    out_ok(y, g[f"ln_{tag}_y"], 1e-5, "ln fwd")
+    y.backward(_t(g[f"ln_{tag}_gy"], dev))
+    grad_ok(x.grad, g[f"ln_{tag}_gx"], what="ln gx")
+    grad_ok(m.weight.grad, g[f"ln_{tag}_gw"], what="ln gw")
+    grad_ok(m.bias.grad, g[f"ln_{tag}_gb"], what="ln gb")
+
+
+@pytest.mark.parametrize("tag,chans", CASES)
+@pytest.mark.parametrize("kind", ["i_lca", "hv_lca"])
+def test_lca_golden(golden, dev, tag, chans, kind):
+    import hvi_cidnet_amd as P
+    g = golden("blocks")
+    p = O.make_params(11, channels=chans)
+    pre = "I_LCA1" if kind == "i_lca" else "HV_LCA1"
+    m = (P.I_LCA if kind == "i_lca" else P.HV_LCA)(chans[1], 2)
+    load(m, p, pre + ".")
+    m.to(dev)
+    x = _t(g[f"{kind}_{tag}_x"], dev).requires_grad_(True)
+    y = _t(g[f"{kind}_{tag}_y"], dev).requires_grad_(True)
+    z = m(x, y)
+    out_ok(z, g[f"{kind}_{tag}_out"], 1e-5, f"{kind} fwd")
+    z.backward(_t(g[f"{kind}_{tag}_gout"], dev))
+    grad_ok(x.grad, g[f"{kind}_{tag}_gx"], what="gx")
+    grad_ok(y.grad, g[f"{kind}_{tag}_gy"], what="gy")
+    for n, prm in m.named_parameters():
+        grad_ok(prm.grad, g[f"{kind}_{tag}_g.{n}"], what=f"{kind} d{n}")
+
+
+@pytest.mark.parametrize("tag,chans", CASES)
+def test_down_up_golden(golden, dev, tag, chans):
+    import hvi_cidnet_amd as P
+    g = golden("blocks")
+    p = O.make_params(11, channels=chans)
+    dn = P.NormDownsample(chans[1], chans[2])
+    load(dn, p, "IE_block2.")
+    dn.to(dev)
+    x = _t(g[f"down_{tag}_x"], dev).requires_grad_(True)
+    y = dn(x)
+    out_ok(y, g[f"down_{tag}_out"], 1e-5, "down fwd")
+    y.backward(_t(g[f"down_{tag}_gout"], dev))
+    grad_ok(x.grad, g[f"down_{tag}_gx"], what="down gx")
+    grad_ok(dn.prelu.weight.grad, g[f"down_{tag}_g.prelu.weight"], what="down dslope")
+    grad_ok(dn.down[0].weight.grad, g[f"down_{tag}_g.down.0.weight"], what="down dW")
+    up = P.NormUpsample(chans[2], chans[1])
+    load(up, p, "ID_block2.")
+    up.to(dev)
+    x = _t(g[f"up_{tag}_x"], dev).requires_grad_(True)
+    s = _t(g[f"up_{tag}_skip"], dev).requires_grad_(True)
+    y = up(x, s)
+    out_ok(y, g[f"up_{tag}_out"], 1e-5, "up fwd")
+    y.backward(_t(g[f"up_{tag}_gout"], dev))
+    grad_ok(x.grad, g[f"up_{tag}_gx"], what="up gx")
+    grad_ok(s.grad, g[f"up_{tag}_gskip"], what="up gskip")
+    grad_ok(up.prelu.weight.grad, g[f"up_{tag}_g.prelu.weight"], what="up dslope")
+    grad_ok(up.up_scale[0].weight.grad, g[f"up_{tag}_g.up_scale.0.weight"], what="up dW3")
+    grad_ok(up.up.weight.grad, g[f"up_{tag}_g.up.weight"], what="up dW1")
+
+
+@pytest.mark.parametrize("tag,chans", CASES)
+def test_cidnet_golden(golden, dev, tag, chans):
+    import hvi_cidnet_amd as P
+    g = golden("model")
+    p = O.make_params(5, channels=chans)
+    m = P.CIDNet(channels=list(chans))
+    load(m, p)
+    m.to(dev)
+    x, gt = _t(g[f"model_{tag}_x"], dev), _t(g[f"model_{tag}_gt"], dev)
+    y = m(x)
+    d = out_ok(y, g[f"model_{tag}_out"], 1e-4, "CIDNet fwd")
+    print(f"CIDNet {tag} fwd max abs diff vs reference: {d:.3e}")
+    loss = (y - gt).abs().mean()
+    assert abs(loss.item() - float(g[f"model_{tag}_loss"])) < 1e-5
+    loss.backward()
+    n_checked = 0
+    for n, prm in m.named_parameters():
+        if n.startswith("I_LCA5."):
+            assert prm.grad is None          # dead block in the reference too
+            continue
+        key = f"model_{tag}_g.{n}"
+        if key in g.files:
+            grad_ok(prm.grad, g[key], rel=2e-4, what=f"d{n}")
+            n_checked += 1
+        s = g[f"model_{tag}_gsum.{n}"]
+        assert abs(prm.grad.double().sum().item() - s[0]) <= 2e-4 * s[1] + 1e-9, n
+    assert n_checked > 30
+
+
+def test_cidnet_config1_400x600(golden, dev):
+    """config 1 of BASELINE.json: one 1x3x400x600 forward, default-style parameters"""
+    import hvi_cidnet_amd as P
+    g = golden("model")
+    m = P.CIDNet()
+    load(m, O.make_params(5, jitter=False))
+    m.to(dev).eval()
+    x = O.synthetic_batch(61, (1, 3, 400, 600)).to(dev)
+    with torch.no_grad():
+        y = m(x)
+    out_ok(y[:, :, ::16, ::16], g["model_c1_out_strided"], 1e-4, "c1 strided")
+    s = g["model_c1_out_sums"]
+    yd = y.double()
+    assert abs(yd.sum().item() - s[0]) <= 1e-5 * s[1]
+    assert abs((yd ** 2).sum().item() - s[2]) <= 1e-5 * s[2]
+
+
+def test_module_surface(dev):
+    import hvi_cidnet_amd as P
+    m = P.CIDNet().to(dev)
+    assert list(m.state_dict().keys()) == list(O.param_shapes().keys())
+    assert sum(p.numel() for p in m.parameters()) == 1975569
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        m(torch.rand(1, 3, 20, 24, device=dev))
+    m.trans.gated, m.trans.gated2, m.trans.alpha, m.trans.alpha_s = True, True, 0.8, 1.3     # eval.py:46-55
+    with torch.no_grad():
+        y = m(torch.rand(1, 3, 16, 24, device=dev))
+    assert y.shape == (1, 3, 16, 24) and torch.isfinite(y).all()
+    assert abs(m.trans.this_k - 0.2) < 1e-6

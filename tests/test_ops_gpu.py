@@ -1,0 +1,149 @@
+"""GPU parity of the individual C-ABI kernels (K3-K11) against plain fp32 PyTorch CPU references of the
+same op on seeded inputs, including ragged sizes (pixel tails, channel tails, unaligned rows)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cidnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, shape, scale=1.0):
+    return (O.synthetic_batch(seed, shape) - 0.5) * (2 * scale)
+
+
+def close(a, b, rel=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    d = (a - b).abs().max().item()
+    tol = rel * b.abs().max().item() + 1e-6
+    assert d <= tol, f"{what}: max diff {d:.3e} > tol {tol:.3e}"
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 36, 36, 8, 12), (1, 95, 36, 13, 17), (2, 36, 190, 20, 30), (1, 144, 766, 5, 15),
+                                         (2, 383, 144, 10, 15), (1, 3, 7, 3, 3), (2, 72, 72, 100, 150)])
+def test_pw_conv_fwd_dgrad_wgrad(dev, B, Ci, Co, H, W):
+    from hvi_cidnet_amd import ops
+    x, w, r = rnd(1, (B, Ci, H, W)), rnd(2, (Co, Ci, 1, 1), 0.3), rnd(3, (B, Co, H, W))
+    gy = rnd(4, (B, Co, H, W))
+    HW = H * W
+    xd, wd, rd, gyd = (t.to(dev) for t in (x, w, r, gy))
+    y = torch.empty_like(rd)
+    ops.pw_conv(xd, 0, Ci * HW, wd, 0, 0, Ci, 1, y, 0, Co * HW, B, Co, Ci, HW, res=rd, r_bs=Co * HW)
+    close(y, F.conv2d(x, w) + r, what="fwd+res")
+    dx = torch.empty_like(xd)
+    ops.pw_conv(gyd, 0, Co * HW, wd, 0, 0, 1, Ci, dx, 0, Ci * HW, B, Ci, Co, HW)
+    close(dx, F.conv_transpose2d(gy, w), what="dgrad")
+    gw = torch.empty_like(wd)
+    ops.pw_wgrad(gyd, 0, Co * HW, xd, 0, Ci * HW, gw, 0, Ci, B, Co, Ci, HW)
+    ref = torch.einsum("bmhw,bnhw->mn", gy.double(), x.double())
+    close(gw.reshape(Co, Ci), ref, what="wgrad")
+    gwb = torch.empty((B, Co, Ci), device=dev)
+    ops.pw_wgrad(gyd, 0, Co * HW, xd, 0, Ci * HW, gwb, 0, Ci, B, Co, Ci, HW, per_sample=True)
+    close(gwb, torch.einsum("bmhw,bnhw->bmn", gy.double(), x.double()), what="wgrad per-sample")
+
+
+def test_pw_conv_per_sample_and_slices(dev):
+    """per-sample weights + reading / writing channel slices of wider tensors (the qkv layout)"""
+    from hvi_cidnet_amd import ops
+    B, C, H, W = 3, 24, 9, 11
+    HW = H * W
+    qkv = rnd(5, (B, 3 * C, H, W))
+    M = rnd(6, (B, C, C), 0.4)
+    out = torch.zeros((B, 2 * C, H, W), device=dev)
+    ops.pw_conv(qkv.to(dev), 2 * C * HW, 3 * C * HW, M.to(dev), 0, C * C, C, 1, out, C * HW, 2 * C * HW, B, C, C, HW)
+    ref = torch.einsum("bmk,bkhw->bmhw", M, qkv[:, 2 * C:])
+    close(out[:, C:], ref, what="per-sample slice")
+    assert out[:, :C].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 36, 8, 12), (1, 144, 50, 75), (2, 12, 7, 9), (1, 72, 100, 150)])
+def test_layernorm(dev, B, C, H, W):
+    from hvi_cidnet_amd import ops
+    x = rnd(7, (B, C, H, W), 2.0)
+    w, b = 1 + rnd(8, (C,), 0.2), rnd(9, (C,), 0.1)
+    gy = rnd(10, (B, C, H, W))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = O.layernorm_cf(xr, wr, br)
+    yr.backward(gy)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.LayerNormCFFn.apply(xd, wd, bd, 1e-6)
+    y.backward(gy.to(dev))
+    close(y, yr, what="fwd")
+    close(xd.grad, xr.grad, what="gx")
+    close(wd.grad, wr.grad, what="gw")
+    close(bd.grad, br.grad, what="gb")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 12, 9, 13), (1, 190, 20, 30), (1, 6, 50, 75), (2, 3, 17, 66)])
+def test_dw3x3(dev, B, C, H, W):
+    from hvi_cidnet_amd import ops
+    x, w, add = rnd(11, (B, C, H, W)), rnd(12, (C, 1, 3, 3), 0.5), rnd(13, (B, C, H, W))
+    cs = C // 3
+    xd, wd, ad = x.to(dev), w.to(dev), add.to(dev)
+    w1, w2 = wd[:cs].contiguous(), wd[cs:].contiguous()
+    y = torch.empty_like(xd)
+    ops.dw3x3(xd, w1, w2, cs, y, B, C, H, W)
+    close(y, F.conv2d(x, w, padding=1, groups=C), what="fwd")
+    ops.dw3x3(xd, w1, w2, cs, y, B, C, H, W, flip=True, addend=ad)
+    close(y, F.conv_transpose2d(x, w, padding=1, groups=C) + add, what="dgrad+add")
+    g = rnd(14, (B, C, H, W))
+    g1, g2 = torch.empty_like(w1), torch.empty_like(w2)
+    ops.dw3x3_wgrad(xd, g.to(dev), g1, g2, cs, B, C, H, W)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, padding=1, groups=C).backward(g)
+    close(torch.cat([g1, g2]), wr.grad, what="wgrad")
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,rep", [(2, 36, 36, 16, 24, False), (1, 72, 144, 10, 15, False), (1, 12, 24, 9, 70, False),
+                                             (2, 3, 36, 16, 24, True), (2, 36, 2, 13, 19, True), (1, 1, 36, 8, 8, True),
+                                             (1, 36, 1, 8, 72, True), (1, 144, 72, 50, 75, False)])
+def test_conv3x3(dev, B, Ci, Co, H, W, rep):
+    from hvi_cidnet_amd import ops
+    x, w = rnd(21, (B, Ci, H, W)), rnd(22, (Co, Ci, 3, 3), 0.3)
+    gy = rnd(23, (B, Co, H, W))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = O.rep_conv3x3(xr, wr) if rep else F.conv2d(xr, wr, padding=1)
+    yr.backward(gy)
+    if rep:
+        xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        y = ops.RepConv3x3Fn.apply(xd, wd)
+        y.backward(gy.to(dev))
+        close(y, yr, what="fwd")
+        close(xd.grad, xr.grad, what="dgrad (replicate)")
+        close(wd.grad, wr.grad, what="wgrad (replicate)")
+    else:
+        xd, wd, gyd = x.to(dev), w.to(dev), gy.to(dev)
+        y = torch.empty_like(gyd)
+        ops.conv3x3(xd, wd, y, B, Co, Ci, H, W, 9 * Ci, 9)
+        close(y, yr, what="fwd")
+        dx = torch.empty_like(xd)
+        ops.conv3x3(gyd, wd, dx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True)
+        close(dx, xr.grad, what="dgrad")
+        gw = torch.empty_like(wd)
+        ops.conv3x3_wgrad(gyd, xd, gw, B, Co, Ci, H, W)
+        close(gw, wr.grad, what="wgrad")
+
+
+@pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 5, 16, 24, 8, 12), (1, 3, 17, 23, 8, 11), (2, 4, 8, 12, 16, 24), (1, 2, 50, 75, 100, 150)])
+def test_bilinear_bwd_and_down(dev, B, C, Hi, Wi, Ho, Wo):
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    x = rnd(31, (B, C, Hi, Wi))
+    g = rnd(32, (B, C, Ho, Wo))
+    xr = x.clone().requires_grad_(True)
+    yr = O.bilinear_ac(xr, (Ho, Wo))
+    yr.backward(g)
+    din = torch.empty((B, C, Hi, Wi), device=dev)
+    gd, xd = g.to(dev), x.to(dev)          # keep the device tensors alive while raw pointers are in flight
+    lib().call("cidnet_bilinear_bwd", ops._p(gd), ops._p(din), B, C, Hi, Wi, Ho, Wo, ops._stream())
+    close(din, xr.grad, what="bilinear adjoint")
+    if Ho == Hi // 2 and Wo == Wi // 2:
+        slope = torch.tensor([0.17])
+        sd = slope.to(dev)
+        pre = torch.empty((B, C, Ho, Wo), device=dev)
+        out = torch.empty_like(pre)
+        lib().call("cidnet_down_prelu_fwd", ops._p(xd), ops._p(sd), ops._p(pre), ops._p(out), B, C, Hi, Wi, ops._stream())
+        close(pre, yr, what="down")
+        close(out, F.prelu(yr, slope), what="down+prelu")
