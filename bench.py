@@ -65,11 +65,15 @@ class OpTimer:
         from hvi_cidnet_amd import _lib
         _lib.lib().call = self._orig
 
-    def table(self):
+    def table(self, by_shape=False):
         torch.cuda.synchronize()
         agg = {}
         for name, args, e0, e1 in self.rec:
-            a = agg.setdefault(name, [0, 0.0])
+            key = name
+            if by_shape:
+                ints = [int(v) for v in args if isinstance(v, int) and not isinstance(v, bool)]
+                key = name + " " + ",".join(str(v) for v in ints[-6:])
+            a = agg.setdefault(key, [0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1)
         return agg
@@ -142,6 +146,8 @@ def main():
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {k:40s} calls/step {v[0] // 2:5d}  ms/step {v[1] / 2:9.3f}  {100 * v[1] / tot:5.1f}%", file=sys.stderr)
             print(f"  sum of kernel families: {tot / 2:.3f} ms/step; wall {1e3 * dt / a.steps:.3f} ms/step", file=sys.stderr)
+            for k, v in sorted(timer.table(by_shape=True).items(), key=lambda kv: -kv[1][1])[:70]:
+                print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
         roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad)",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
