@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kR = 2;      // output rows per wave
-constexpr int kKC = 16;    // input channels staged per chunk (4 k-groups)
+constexpr int kKC = 36;    // input channels staged per chunk (9 k-groups)
 
 struct C3Args {
   const float* X; long x_bs;
@@ -32,70 +32,57 @@ struct C3Args {
   int nmb;         // number of m-blocks (blockIdx.z = b*nmb + mb)
 };
 
-__device__ __forceinline__ float dpp_row_shr1(float src, float old) {   // lane c <- lane c-1 (c>0); lane 0 keeps old
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                               0x111, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float dpp_row_shl1(float src, float old) {   // lane c <- lane c+1 (c<15); lane 15 keeps old
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                               0x101, 0xF, 0xF, false));
-}
-
 struct Win6 {
   float v[6];
 };
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };
 
-// window x0-1 .. x0+4 of one input row for this lane's channel; `chan_ok` false => zeros
-__device__ __forceinline__ Win6 load_win(const float* __restrict__ plane, int yy, int x0, int c, int H, int W, bool chan_ok,
-                                         bool replicate) {
+// window x0-1 .. x0+4 of input row yy (zero or replicate outside the image).  Interior lanes issue
+// one 16 B and one 8 B load; only lanes touching the left/right image border take the scalar path.
+__device__ __forceinline__ Win6 load_win(const float* __restrict__ plane, int yy, int x0, int H, int W, bool replicate) {
   Win6 r;
 #pragma unroll
   for (int i = 0; i < 6; ++i) r.v[i] = 0.f;
-  bool row_ok = chan_ok;
   if (yy < 0 || yy >= H) {
-    if (replicate) yy = yy < 0 ? 0 : H - 1; else row_ok = false;
+    if (!replicate) return r;
+    yy = yy < 0 ? 0 : H - 1;
   }
-  f32x4 m = {0.f, 0.f, 0.f, 0.f};
-  float el = 0.f, er = 0.f;
-  if (row_ok) {
-    const float* row = plane + (long)yy * W;
-    if (x0 + 3 < W) {
-      m = load4u(row + x0);
-    } else {
+  const float* row = plane + (long)yy * W;
+  if (x0 >= 1 && x0 + 5 <= W) {
+    const f4u a = *reinterpret_cast<const f4u*>(row + x0 - 1);
+    const f2u b = *reinterpret_cast<const f2u*>(row + x0 + 3);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y;
+  } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int x = x0 + e;
-        if (x < W) m[e] = row[x]; else if (replicate) m[e] = row[W - 1];
-      }
-    }
-    if (c == 0) {
-      if (x0 > 0) el = row[x0 - 1]; else if (replicate) el = row[0];
-    }
-    if (c == 15) {
-      if (x0 + 4 < W) er = row[x0 + 4]; else if (replicate) er = row[W - 1];
+    for (int i = 0; i < 6; ++i) {
+      int x = x0 - 1 + i;
+      if (x < 0) { if (!replicate) continue; x = 0; }
+      if (x >= W) { if (!replicate) continue; x = W - 1; }
+      r.v[i] = row[x];
     }
   }
-  r.v[1] = m[0]; r.v[2] = m[1]; r.v[3] = m[2]; r.v[4] = m[3];
-  r.v[0] = dpp_row_shr1(m[3], el);
-  r.v[5] = dpp_row_shl1(m[0], er);
   return r;
 }
 
-template <int MT>
+// LOGX: log2 of the lanes (x 4 pixels) a 16-lane group spends on x; the other 16>>LOGX lanes take
+// further rows, so narrow images (W = 75, 150) do not waste most of a 64-pixel-wide tile.
+template <int MT, int LOGX>
 __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   extern __shared__ float As[];                 // [kKC][9][ldA]
   constexpr int MB = 16 * MT;
   constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, j = lane >> 4;
   const int b = blockIdx.z / a.nmb, mb = blockIdx.z - b * a.nmb;
   const int m0 = mb * MB;
-  const int x0 = blockIdx.x * 64 + 4 * c;
-  const int yw = blockIdx.y * (4 * kR) + wave * kR;      // first output row of this wave
+  const int x0 = blockIdx.x * (XL * 4) + 4 * (c & (XL - 1));
+  const int yw = blockIdx.y * (4 * NY * kR) + wave * (NY * kR) + (c >> LOGX) * kR;   // first output row of this lane
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
   const float* Xb = a.X + (long)b * a.x_bs;
   const bool rep = a.replicate != 0;
+  const bool wave_live = blockIdx.y * (4 * NY * kR) + wave * (NY * kR) < H;
 
   f32x4 acc[kR][MT][4];
 #pragma unroll
@@ -119,14 +106,23 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
       As[(kk * 9 + t) * ldA + mm] = v;
     }
     __syncthreads();
-    if (yw >= H) continue;                     // wave-uniform; still takes part in the barriers above
+    if (!wave_live) continue;                    // wave-uniform; the wave still joins the barriers above
+    // channels past K are clamped to a valid plane: their weights are zero in LDS
+    Win6 nxt[kR + 2];
+    {
+      const float* plane = Xb + (long)min(kc0 + j, a.K - 1) * HW;
+#pragma unroll
+      for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+    }
     for (int g = 0; g < ng; ++g) {
-      const int ch = kc0 + 4 * g + j;
-      const bool chan_ok = (4 * g + j) < kcn;
-      const float* plane = Xb + (long)(chan_ok ? ch : 0) * HW;
       Win6 win[kR + 2];
 #pragma unroll
-      for (int iy = 0; iy < kR + 2; ++iy) win[iy] = load_win(plane, yw - 1 + iy, x0, c, H, W, chan_ok, rep);
+      for (int iy = 0; iy < kR + 2; ++iy) win[iy] = nxt[iy];
+      if (g + 1 < ng) {
+        const float* plane = Xb + (long)min(kc0 + 4 * (g + 1) + j, a.K - 1) * HW;
+#pragma unroll
+        for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+      }
       float av[9][MT];
 #pragma unroll
       for (int t = 0; t < 9; ++t)
@@ -173,15 +169,32 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   }
 }
 
-template <int MT>
-int launch_c3(const C3Args& a, int B, hipStream_t s) {
+template <int MT, int LOGX>
+int launch_c3x(const C3Args& a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT;
   constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
-  const size_t lds = (size_t)kKC * 9 * ldA * sizeof(float);
-  dim3 grid((unsigned)((a.W + 63) / 64), (unsigned)((a.H + 4 * kR - 1) / (4 * kR)), (unsigned)(B * a.nmb));
-  hipLaunchKernelGGL((conv3_kernel<MT>), grid, dim3(kThreads), lds, s, a);
+  constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
+  const int kc = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
+  const size_t lds = (size_t)kc * 9 * ldA * sizeof(float);
+  dim3 grid((unsigned)((a.W + XL * 4 - 1) / (XL * 4)), (unsigned)((a.H + 4 * NY * kR - 1) / (4 * NY * kR)), (unsigned)(B * a.nmb));
+  hipLaunchKernelGGL((conv3_kernel<MT, LOGX>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+template <int MT>
+int launch_c3(const C3Args& a, int B, hipStream_t s) {
+  // pick the x extent of a lane group (64 / 32 / 16 pixels) that wastes the fewest columns
+  int best = 4;
+  long best_cols = 1L << 60;
+  for (int lx = 4; lx >= 2; --lx) {
+    const int tw = 4 << lx;
+    const long cols = (long)((a.W + tw - 1) / tw) * tw;
+    if (cols < best_cols) { best_cols = cols; best = lx; }
+  }
+  if (best == 4) return launch_c3x<MT, 4>(a, B, s);
+  if (best == 3) return launch_c3x<MT, 3>(a, B, s);
+  return launch_c3x<MT, 2>(a, B, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -193,7 +206,7 @@ int launch_c3(const C3Args& a, int B, hipStream_t s) {
 struct C3WgArgs {
   const float* dY; long dy_bs;
   const float* X; long x_bs;
-  float* slabs;     // [B][chunks][4][M*N*9]
+  float* slabs;     // [B][chunks][M*N*9]
   int M, N, H, W;
   int replicate;
   int rr;           // rows per chunk
@@ -235,6 +248,7 @@ __device__ __forceinline__ Win10 load_win10(const float* __restrict__ plane, int
 
 template <int MT>
 __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
+  extern __shared__ float red[];                 // [4 waves][MT*4][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, j = lane >> 4;
   const int b = blockIdx.z;
@@ -254,32 +268,42 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (seg_ok) {
-    const int n = n0 + r;
-    const bool n_ok = n < a.N;
-    const float* xpl = a.X + (long)b * a.x_bs + (long)(n_ok ? n : 0) * HW;
-    Win10 w0 = load_win10(xpl, ya - 1, xs, H, W, n_ok, rep);
-    Win10 w1 = load_win10(xpl, ya, xs, H, W, n_ok, rep);
-    for (int y = ya; y < yb; ++y) {
-      const Win10 w2 = load_win10(xpl, y + 1, xs, H, W, n_ok, rep);
-      float av[MT][8];
+  if (seg_ok && ya < yb) {
+    // rows / columns past M / N are clamped to a valid plane: they only reach accumulator entries
+    // that are never stored
+    const float* xpl = a.X + (long)b * a.x_bs + (long)min(n0 + r, a.N - 1) * HW;
+    const float* ypl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ypl[mt] = a.dY + (long)b * a.dy_bs + (long)min(m0 + mt * 16 + r, a.M - 1) * HW;
+    auto load_dy = [&](int y, float (&av)[MT][8]) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + mt * 16 + r;
-        const float* row = a.dY + (long)b * a.dy_bs + (long)(m < a.M ? m : 0) * HW + (long)y * W;
+        const float* row = ypl[mt] + (long)y * W;
+        if (xs + 7 < W) {
+          const f32x4 p = load4u(row + xs), q = load4u(row + xs + 4);
+          av[mt][0] = p[0]; av[mt][1] = p[1]; av[mt][2] = p[2]; av[mt][3] = p[3];
+          av[mt][4] = q[0]; av[mt][5] = q[1]; av[mt][6] = q[2]; av[mt][7] = q[3];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) av[mt][e] = 0.f;
-        if (m < a.M) {
-          if (xs + 7 < W) {
-            const f32x4 p = load4u(row + xs), q = load4u(row + xs + 4);
-            av[mt][0] = p[0]; av[mt][1] = p[1]; av[mt][2] = p[2]; av[mt][3] = p[3];
-            av[mt][4] = q[0]; av[mt][5] = q[1]; av[mt][6] = q[2]; av[mt][7] = q[3];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (xs + e < W) av[mt][e] = row[xs + e];
-          }
+          for (int e = 0; e < 8; ++e) av[mt][e] = (xs + e < W) ? row[xs + e] : 0.f;
         }
+      }
+    };
+    Win10 w0 = load_win10(xpl, ya - 1, xs, H, W, true, rep);
+    Win10 w1 = load_win10(xpl, ya, xs, H, W, true, rep);
+    Win10 w2n = load_win10(xpl, ya + 1, xs, H, W, true, rep);
+    float avn[MT][8];
+    load_dy(ya, avn);
+    for (int y = ya; y < yb; ++y) {
+      const Win10 w2 = w2n;
+      float av[MT][8];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[mt][e] = avn[mt][e];
+      if (y + 1 < yb) {                           // prefetch the next row's operands
+        w2n = load_win10(xpl, y + 2, xs, H, W, true, rep);
+        load_dy(y + 1, avn);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -295,16 +319,29 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
     }
   }
 
-  float* slab = a.slabs + ((((long)b * gridDim.x + blockIdx.x) * 4 + wave) * (long)a.M) * a.N * 9;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
+  // sum the four waves' tiles through LDS (one tap per round), one slab per block
+  float* slab = a.slabs + (((long)b * gridDim.x + blockIdx.x) * (long)a.M) * a.N * 9;
+  constexpr int TILE = MT * 4;
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int m = m0 + mt * 16 + j * 4 + reg, n = n0 + r;
-        if (m < a.M && n < a.N) slab[((long)m * a.N + n) * 9 + t] = acc[t][mt][reg];
+        float v = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 9; ++tt) v = (tt == t) ? acc[tt][mt][reg] : v;    // static register indexing
+        red[(wave * TILE + mt * 4 + reg) * 64 + lane] = v;
       }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TILE * 64; idx += kThreads) {
+      const float v = (red[idx] + red[TILE * 64 + idx]) + (red[2 * TILE * 64 + idx] + red[3 * TILE * 64 + idx]);
+      const int l = idx & 63, q = idx >> 6;
+      const int reg = q & 3, mt = q >> 2;
+      const int m = m0 + mt * 16 + (l >> 4) * 4 + reg, n = n0 + (l & 15);
+      if (m < a.M && n < a.N) slab[((long)m * a.N + n) * 9 + t] = v;
+    }
+  }
 }
 
 __global__ void c3_reduce_kernel(const float* __restrict__ slabs, int n_red, long ne, float* __restrict__ out) {
@@ -317,7 +354,17 @@ __global__ void c3_reduce_kernel(const float* __restrict__ slabs, int n_red, lon
   out[i] = t0 + t1;
 }
 
-inline int wg_rows(int H) { return H >= 200 ? 64 : 32; }
+// rows per chunk: enough blocks to fill the chip (>= ~1024) without going below 16 rows per block
+inline int wg_rows(int B, int M, int N, int H, int W) {
+  const int T = (M + 15) / 16;
+  const int nblk = (T + 2) / 3;
+  const int MT = (T + nblk - 1) / nblk;
+  const int per_chunk = (((W + 31) / 32 + 3) / 4) * ((T + MT - 1) / MT) * ((N + 15) / 16) * B;
+  int nrc = (1024 + per_chunk - 1) / per_chunk;
+  const int max_nrc = H / 16 > 0 ? H / 16 : 1;
+  nrc = nrc < 1 ? 1 : (nrc > max_nrc ? max_nrc : nrc);
+  return (H + nrc - 1) / nrc;
+}
 
 // Border correction of the data gradient of (ReplicationPad2d(1) + valid 3x3 conv): the zero-pad
 // data gradient misses the taps that read a replicated border pixel; add them in place.
@@ -384,9 +431,9 @@ int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w
 }
 
 long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W) {
-  const int rr = wg_rows(H);
+  const int rr = wg_rows(B, M, N, H, W);
   const long chunks = (long)(((W + 31) / 32 + 3) / 4) * ((H + rr - 1) / rr);
-  return (long)B * chunks * 4 * M * N * 9;
+  return (long)B * chunks * M * N * 9;
 }
 
 int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int replicate, float* dW, float* ws,
@@ -395,7 +442,7 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
   if (ws_floats < cidnet_conv3x3_wgrad_ws_floats(B, M, N, H, W)) return CIDNET_ERR_WS;
   C3WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.H = H; a.W = W;
-  a.replicate = replicate; a.rr = wg_rows(H);
+  a.replicate = replicate; a.rr = wg_rows(B, M, N, H, W);
   a.nseg4 = ((W + 31) / 32 + 3) / 4;
   a.nnt = (N + 15) / 16;
   const int chunks = a.nseg4 * ((H + a.rr - 1) / a.rr);
@@ -405,12 +452,13 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
   const int nmb = (T + MT - 1) / MT;
   dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnt), (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
-  if (MT == 1) hipLaunchKernelGGL((conv3_wgrad_kernel<1>), grid, dim3(kThreads), 0, s, a);
-  else if (MT == 2) hipLaunchKernelGGL((conv3_wgrad_kernel<2>), grid, dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL((conv3_wgrad_kernel<3>), grid, dim3(kThreads), 0, s, a);
+  const size_t lds = (size_t)4 * MT * 4 * 64 * sizeof(float);
+  if (MT == 1) hipLaunchKernelGGL((conv3_wgrad_kernel<1>), grid, dim3(kThreads), lds, s, a);
+  else if (MT == 2) hipLaunchKernelGGL((conv3_wgrad_kernel<2>), grid, dim3(kThreads), lds, s, a);
+  else hipLaunchKernelGGL((conv3_wgrad_kernel<3>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   const long ne = (long)M * N * 9;
-  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, ws, B * chunks * 4, ne, dW);
+  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, ws, B * chunks, ne, dW);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -1,20 +1,123 @@
 // K3: channels-first LayerNorm (per-pixel statistics over C), forward and backward.
 // Reference: LayerNorm.forward, net/transformer_utils.py:24-29 (biased variance, eps inside sqrt).
 //
-// NCHW makes the reduction axis (C) the strided one: a lane owns 4 consecutive pixels and walks
-// the C planes, so every access is a coalesced 16 B/lane row segment and the per-pixel reductions
-// need no cross-lane traffic at all.  The cross-pixel reductions of the backward (d weight, d bias)
-// use wavefront shuffles, one private LDS row per wave and a fixed-order two-level sum
-// (bitwise reproducible).  HBM-bound: fwd reads x once from HBM (the two re-reads of the 4-pixel
-// column hit L1/L2) and writes y; bwd reads x, gy and writes gx.
+// NCHW makes the reduction axis (C) the strided one: a lane owns VEC consecutive pixels and walks
+// the C planes, so every access is a coalesced row segment and the per-pixel reductions need no
+// cross-lane traffic.  The whole C-column of a lane is held in registers (C*VEC = 144 floats for
+// the CIDNet widths 36/72/144), so x is read from HBM exactly once; a generic multi-pass kernel
+// covers other widths.  The backward is two kernels: a per-pixel one (gx; reads x, gy once) and a
+// channel-major one (d weight, d bias; block = one channel x one pixel chunk, fixed-order two-level
+// sum => bitwise reproducible, no atomics).
 #include "common.h"
 
 namespace cidnet {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 2048;
 
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+  typedef f32x4 T;
+  static __device__ __forceinline__ T ld(const float* p) { return load4u(p); }
+  static __device__ __forceinline__ void st(float* p, T v) { store4u(p, v); }
+};
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <> struct Vec<2> {
+  typedef f32x2 T;
+  static __device__ __forceinline__ T ld(const float* p) { f2u v = *reinterpret_cast<const f2u*>(p); T r = {v.x, v.y}; return r; }
+  static __device__ __forceinline__ void st(float* p, T v) { f2u s; s.x = v[0]; s.y = v[1]; *reinterpret_cast<f2u*>(p) = s; }
+};
+typedef float f32x1 __attribute__((ext_vector_type(1)));
+template <> struct Vec<1> {
+  typedef float T;
+  static __device__ __forceinline__ T ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+};
+template <int VEC> __device__ __forceinline__ typename Vec<VEC>::T vrsqrt_eps(typename Vec<VEC>::T v, float invC, float eps);
+template <> __device__ __forceinline__ float vrsqrt_eps<1>(float v, float invC, float eps) { return 1.0f / sqrtf(v * invC + eps); }
+template <> __device__ __forceinline__ f32x2 vrsqrt_eps<2>(f32x2 v, float invC, float eps) {
+  f32x2 r = {1.0f / sqrtf(v[0] * invC + eps), 1.0f / sqrtf(v[1] * invC + eps)};
+  return r;
+}
+template <> __device__ __forceinline__ f32x4 vrsqrt_eps<4>(f32x4 v, float invC, float eps) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = 1.0f / sqrtf(v[e] * invC + eps);
+  return r;
+}
+
+// ---- register-resident column kernels (HW % VEC == 0) -----------------------------------------
+template <int C, int VEC>
+__global__ __launch_bounds__(kThreads) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, int B,
+                                                              long HW, float eps) {
+  typedef typename Vec<VEC>::T V;
+  const long nq = HW / VEC;
+  const long total = (long)B * nq;
+  const float invC = 1.0f / (float)C;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / nq, p = (it - b * nq) * VEC;
+    const float* xb = x + b * C * HW + p;
+    V col[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) col[c] = Vec<VEC>::ld(xb + (long)c * HW);
+    V s = col[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) s += col[c];
+    const V u = s * invC;
+    V v = (col[0] - u) * (col[0] - u);
+#pragma unroll
+    for (int c = 1; c < C; ++c) { const V d = col[c] - u; v += d * d; }
+    const V rs = vrsqrt_eps<VEC>(v, invC, eps);
+    float* yb = y + b * C * HW + p;
+#pragma unroll
+    for (int c = 0; c < C; ++c) Vec<VEC>::st(yb + (long)c * HW, (col[c] - u) * rs * w[c] + bias[c]);
+    if (mean) { Vec<VEC>::st(mean + b * HW + p, u); Vec<VEC>::st(rstd + b * HW + p, rs); }
+  }
+}
+
+// gx = rstd * (g*w - mean_c(g*w) - xhat * mean_c(g*w*xhat)); xhat (and g*w if CACHE_G) stay in
+// registers; without CACHE_G the second use of g re-reads it (it was just touched: L1/L2 hit)
+template <int C, int VEC, bool CACHE_G>
+__global__ __launch_bounds__(kThreads) void ln_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ gy, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ gx, int B,
+                                                              long HW) {
+  typedef typename Vec<VEC>::T V;
+  const long nq = HW / VEC;
+  const long total = (long)B * nq;
+  const float invC = 1.0f / (float)C;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / nq, p = (it - b * nq) * VEC;
+    const float* xb = x + b * C * HW + p;
+    const float* gb = gy + b * C * HW + p;
+    const V u = Vec<VEC>::ld(mean + b * HW + p), rs = Vec<VEC>::ld(rstd + b * HW + p);
+    V xh[C], gw[CACHE_G ? C : 1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xh[c] = Vec<VEC>::ld(xb + (long)c * HW);
+    V s1 = u * 0.f, s2 = s1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const V g = Vec<VEC>::ld(gb + (long)c * HW) * w[c];
+      if (CACHE_G) gw[c] = g;
+      xh[c] = (xh[c] - u) * rs;
+      s1 += g;
+      s2 += g * xh[c];
+    }
+    s1 = s1 * invC; s2 = s2 * invC;
+    float* gxb = gx + b * C * HW + p;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const V g = CACHE_G ? gw[c] : Vec<VEC>::ld(gb + (long)c * HW) * w[c];
+      Vec<VEC>::st(gxb + (long)c * HW, rs * (g - s1 - xh[c] * s2));
+    }
+  }
+}
+
+// ---- generic multi-pass kernels (any C, any HW) ---------------------------------------------------
 __device__ __forceinline__ f32x4 ld4(const float* row, long p, int n) {
   if (n == 4) return load4u(row + p);
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -45,80 +148,89 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float* __restric
       const f32x4 d = ld4(xb + (long)c * HW, p, n) - u;
       v += d * d;
     }
-    f32x4 rs;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(v[e] * invC + eps);
+    const f32x4 rs = vrsqrt_eps<4>(v, invC, eps);
     float* yb = y + b * C * HW;
-    for (int c = 0; c < C; ++c) {
-      const f32x4 d = (ld4(xb + (long)c * HW, p, n) - u) * rs;
-      st4(yb + (long)c * HW, p, n, d * w[c] + bias[c]);
-    }
+    for (int c = 0; c < C; ++c) st4(yb + (long)c * HW, p, n, (ld4(xb + (long)c * HW, p, n) - u) * rs * w[c] + bias[c]);
     if (mean) { st4(mean + b * HW, p, n, u); st4(rstd + b * HW, p, n, rs); }
   }
 }
 
-// gx = rstd * (g*w - mean_c(g*w) - xhat * mean_c(g*w*xhat));  per-block partials of gw, gb.
 __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ gy, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, float* __restrict__ gx,
-                                                          float* __restrict__ part, int B, int C, long HW) {
-  extern __shared__ float sm[];                 // [4 waves][2C]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* mine = sm + wave * 2 * C;
-  for (int i = lane; i < 2 * C; i += 64) mine[i] = 0.f;
+                                                          const float* __restrict__ rstd, float* __restrict__ gx, int B, int C,
+                                                          long HW) {
   const long nq = (HW + 3) >> 2;
   const long total = (long)B * nq;
-  const long stride = (long)gridDim.x * blockDim.x;
-  const long iters = (total + stride - 1) / stride;   // uniform trip count: shuffles need every lane
   const float invC = 1.0f / (float)C;
-  for (long i = 0; i < iters; ++i) {
-    const long it = i * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = it < total;
-    const long b = live ? it / nq : 0, p = live ? (it - b * nq) << 2 : 0;
-    const int n = live ? ((HW - p >= 4) ? 4 : (int)(HW - p)) : 0;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / nq, p = (it - b * nq) << 2;
+    const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
     const float* xb = x + b * C * HW;
     const float* gb = gy + b * C * HW;
-    f32x4 u = {0.f, 0.f, 0.f, 0.f}, rs = u, s1 = u, s2 = u;
-    if (live) { u = ld4(mean + b * HW, p, n); rs = ld4(rstd + b * HW, p, n); }
+    const f32x4 u = ld4(mean + b * HW, p, n), rs = ld4(rstd + b * HW, p, n);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     for (int c = 0; c < C; ++c) {
-      f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = g;
-      if (live) { g = ld4(gb + (long)c * HW, p, n); xh = (ld4(xb + (long)c * HW, p, n) - u) * rs; }
-      const f32x4 gw = g * w[c];
+      const f32x4 gw = ld4(gb + (long)c * HW, p, n) * w[c];
       s1 += gw;
-      s2 += gw * xh;
-      const f32x4 t = g * xh;
-      const float pw = wave_sum((t[0] + t[1]) + (t[2] + t[3]));
-      const float pb = wave_sum((g[0] + g[1]) + (g[2] + g[3]));
-      if (lane == 0) { mine[c] += pw; mine[C + c] += pb; }
+      s2 += gw * ((ld4(xb + (long)c * HW, p, n) - u) * rs);
     }
-    if (live && gx) {
-      s1 = s1 * invC; s2 = s2 * invC;
-      float* gxb = gx + b * C * HW;
-      for (int c = 0; c < C; ++c) {
-        const f32x4 g = ld4(gb + (long)c * HW, p, n);
-        const f32x4 xh = (ld4(xb + (long)c * HW, p, n) - u) * rs;
-        st4(gxb + (long)c * HW, p, n, rs * (g * w[c] - s1 - xh * s2));
-      }
+    s1 = s1 * invC; s2 = s2 * invC;
+    float* gxb = gx + b * C * HW;
+    for (int c = 0; c < C; ++c) {
+      const f32x4 xh = (ld4(xb + (long)c * HW, p, n) - u) * rs;
+      st4(gxb + (long)c * HW, p, n, rs * (ld4(gb + (long)c * HW, p, n) * w[c] - s1 - xh * s2));
     }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x)
-    part[(long)blockIdx.x * 2 * C + i] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
 }
 
-__global__ void ln_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ gw,
-                                 float* __restrict__ gb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  float t = 0.f;
-  for (int k = 0; k < nblk; ++k) t += part[(long)k * 2 * C + i];
-  if (i < C) gw[i] = t; else gb[i - C] = t;
+// ---- d weight / d bias: block = (pixel chunk, channel) ---------------------------------------------
+__global__ __launch_bounds__(kThreads) void ln_wb_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ part, int B, int C, long HW, int nchunk) {
+  __shared__ float red[kThreads / 64];
+  const int c = blockIdx.y;
+  const long nq = (HW + 3) >> 2;
+  float aw = 0.f, ab = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* xp = x + ((long)b * C + c) * HW;
+    const float* gp = gy + ((long)b * C + c) * HW;
+    const float* mp = mean + (long)b * HW;
+    const float* rp = rstd + (long)b * HW;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)nchunk * blockDim.x) {
+      const long p = q << 2;
+      const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
+      const f32x4 g = ld4(gp, p, n);
+      const f32x4 xh = (ld4(xp, p, n) - ld4(mp, p, n)) * ld4(rp, p, n);
+      const f32x4 t = g * xh;
+      aw += (t[0] + t[1]) + (t[2] + t[3]);
+      ab += (g[0] + g[1]) + (g[2] + g[3]);
+    }
+  }
+  const float sw = block_sum(aw, red);
+  const float sb = block_sum(ab, red);
+  if (threadIdx.x == 0) { part[((long)c * nchunk + blockIdx.x) * 2] = sw; part[((long)c * nchunk + blockIdx.x) * 2 + 1] = sb; }
 }
 
-inline int grid_for(int B, long HW) {
-  const long quads = (long)B * ((HW + 3) >> 2);
-  long g = (quads + kThreads - 1) / kThreads;
+__global__ void ln_wb_reduce_kernel(const float* __restrict__ part, int nchunk, int C, float* __restrict__ gw,
+                                    float* __restrict__ gb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nchunk; ++k) { a += part[((long)c * nchunk + k) * 2]; b += part[((long)c * nchunk + k) * 2 + 1]; }
+  gw[c] = a; gb[c] = b;
+}
+
+inline int grid_for(long items) {
+  long g = (items + kThreads - 1) / kThreads;
   return (int)(g > kMaxBlocks ? kMaxBlocks : (g < 1 ? 1 : g));
+}
+
+inline int wb_chunks(int B, int C, long HW) {
+  // aim for ~2048 blocks over (chunk, channel) without dropping below 1024 pixels per thread-block pass
+  long per = ((HW + 3) / 4 + kThreads - 1) / kThreads;
+  long want = (2048 + C - 1) / C;
+  long n = per < want ? per : want;
+  return (int)(n < 1 ? 1 : n);
 }
 
 }  // namespace
@@ -132,23 +244,50 @@ int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, flo
                      int C, long HW, float eps, void* stream) {
   CIDNET_CHECK_ARG(x && weight && bias && y && B > 0 && C > 0 && HW > 0);
   CIDNET_CHECK_ARG((mean == nullptr) == (rstd == nullptr));
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(B, HW)), dim3(kThreads), 0, (hipStream_t)stream, x, weight, bias, y,
-                     mean, rstd, B, C, HW, eps);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 36 && HW % 4 == 0)
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 4>), dim3(grid_for((long)B * HW / 4)), dim3(kThreads), 0, s, x, weight, bias, y,
+                       mean, rstd, B, HW, eps);
+  else if (C == 72 && HW % 2 == 0)
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<72, 2>), dim3(grid_for((long)B * HW / 2)), dim3(kThreads), 0, s, x, weight, bias, y,
+                       mean, rstd, B, HW, eps);
+  else if (C == 144)
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<144, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
+                       mean, rstd, B, HW, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, s, x, weight, bias, y, mean,
+                       rstd, B, C, HW, eps);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
-long cidnet_ln_cf_bwd_ws_floats(int C) { return (long)kMaxBlocks * 2 * C; }
+long cidnet_ln_cf_bwd_ws_floats(int C) { return 2L * 2048 + 4L * C * 64; }
 
 int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd, float* gx,
                      float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW, void* stream) {
   CIDNET_CHECK_ARG(x && weight && gy && mean && rstd && gw && gb && ws && B > 0 && C > 0 && HW > 0);
-  if (ws_floats < cidnet_ln_cf_bwd_ws_floats(C)) return CIDNET_ERR_WS;
-  const int grid = grid_for(B, HW);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(kThreads), (size_t)8 * C * sizeof(float), (hipStream_t)stream, x,
-                     weight, gy, mean, rstd, gx, ws, B, C, HW);
+  const int nchunk = wb_chunks(B, C, HW);
+  if (ws_floats < 2L * C * nchunk) return CIDNET_ERR_WS;
+  hipStream_t s = (hipStream_t)stream;
+  if (gx) {
+    if (C == 36 && HW % 2 == 0)
+      hipLaunchKernelGGL((ln_bwd_reg_kernel<36, 2, true>), dim3(grid_for((long)B * HW / 2)), dim3(kThreads), 0, s, x, weight, gy, mean,
+                         rstd, gx, B, HW);
+    else if (C == 72)
+      hipLaunchKernelGGL((ln_bwd_reg_kernel<72, 1, true>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, gy, mean,
+                         rstd, gx, B, HW);
+    else if (C == 144)
+      hipLaunchKernelGGL((ln_bwd_reg_kernel<144, 1, false>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, gy,
+                         mean, rstd, gx, B, HW);
+    else
+      hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, s, x, weight, gy, mean, rstd,
+                         gx, B, C, HW);
+    CIDNET_LAUNCH_STATUS();
+  }
+  hipLaunchKernelGGL(ln_wb_kernel, dim3((unsigned)nchunk, (unsigned)C), dim3(kThreads), 0, s, x, gy, mean, rstd, ws, B, C, HW,
+                     nchunk);
   CIDNET_LAUNCH_STATUS();
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, grid, C, gw, gb);
+  hipLaunchKernelGGL(ln_wb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nchunk, C, gw, gb);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   const long HW = a.HW;
   const float* Xb = a.X + (long)b * a.x_bs;
   const float* Wb = a.Wt + (long)b * a.w_bs;
+  const bool full = (long)blockIdx.x * 256 + 256 <= HW;      // block-uniform
 
   f32x4 acc[MT][4];
 #pragma unroll
@@ -108,15 +109,33 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
       As[kk * ldA + mm] = v;
     }
     __syncthreads();
-    f32x4 xv = load_px4(Xb + (long)(kc0 + j) * HW, p0, HW, j < kcn);
-    for (int k4 = 0; k4 < kcn4; k4 += 4) {
-      const f32x4 xc = xv;
-      if (k4 + 4 < kcn4) xv = load_px4(Xb + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn);
+    // Rows past K are clamped to a valid row: their A entries are zero-padded in LDS, so no
+    // predicate is needed; only the last pixel block of a plane takes the bounds-checked loads.
+    const int klast = kcn - 1;
+    if (full) {
+      const float* xp = Xb + (long)kc0 * HW + p0;
+      f32x4 xv = load4u(xp + (long)min(j, klast) * HW);
+      for (int k4 = 0; k4 < kcn4; k4 += 4) {
+        const f32x4 xc = xv;
+        if (k4 + 4 < kcn4) xv = load4u(xp + (long)min(k4 + 4 + j, klast) * HW);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float av = As[(k4 + j) * ldA + mt * 16 + c];
+        for (int mt = 0; mt < MT; ++mt) {
+          const float av = As[(k4 + j) * ldA + mt * 16 + c];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+        }
+      }
+    } else {
+      f32x4 xv = load_px4(Xb + (long)(kc0 + j) * HW, p0, HW, j < kcn);
+      for (int k4 = 0; k4 < kcn4; k4 += 4) {
+        const f32x4 xc = xv;
+        if (k4 + 4 < kcn4) xv = load_px4(Xb + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float av = As[(k4 + j) * ldA + mt * 16 + c];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+        }
       }
     }
   }
@@ -192,13 +211,14 @@ int dispatch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
 struct WgArgs {
   const float* dY; long dy_bs;
   const float* X; long x_bs;
-  float* slabs;         // [B][chunks][4 waves][M*N]
+  float* slabs;         // [B][chunks][M*N]
   int M, N; long HW; int pch;   // pixels per block (multiple of 128)
   int nnb;              // number of n-blocks
 };
 
 template <int MT, int NT>
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
+  extern __shared__ float red[];                 // [4 waves][MT*NT*4 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, j = lane >> 4;
   const int b = blockIdx.z;
@@ -209,6 +229,12 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   const long pend = (pbeg + a.pch < HW) ? pbeg + a.pch : HW;
   const float* dYb = a.dY + (long)b * a.dy_bs;
   const float* Xb = a.X + (long)b * a.x_bs;
+  const float* arow[MT];
+  const float* brow[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = dYb + (long)min(m0 + mt * 16 + r, a.M - 1) * HW;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) brow[nt] = Xb + (long)min(n0 + nt * 16 + r, a.N - 1) * HW;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -216,23 +242,32 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (long p = pbeg + wave * 32; p < pend; p += 128) {
-    const long pl = p + 8 * j;
-    f32x4 av[MT][2], bv[NT][2];
+  // Rows past M / N are clamped to a valid row: they only feed accumulator rows / columns that are
+  // never stored.  Steps that lie fully inside [pbeg, pend) use unconditional 16 B loads.
+  f32x4 av[MT][2], bv[NT][2];
+  long p = pbeg + wave * 32;
+  auto load_step = [&](long ps) {
+    const long pl = ps + 8 * j;
+    if (ps + 32 <= pend) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + mt * 16 + r;
-      const float* row = dYb + (long)m * HW;
-      av[mt][0] = load_px4(row, pl, pend, m < a.M);
-      av[mt][1] = load_px4(row, pl + 4, pend, m < a.M);
-    }
+      for (int mt = 0; mt < MT; ++mt) { av[mt][0] = load4u(arow[mt] + pl); av[mt][1] = load4u(arow[mt] + pl + 4); }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + nt * 16 + r;
-      const float* row = Xb + (long)n * HW;
-      bv[nt][0] = load_px4(row, pl, pend, n < a.N);
-      bv[nt][1] = load_px4(row, pl + 4, pend, n < a.N);
+      for (int nt = 0; nt < NT; ++nt) { bv[nt][0] = load4u(brow[nt] + pl); bv[nt][1] = load4u(brow[nt] + pl + 4); }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { av[mt][0] = load_px4(arow[mt], pl, pend, true); av[mt][1] = load_px4(arow[mt], pl + 4, pend, true); }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { bv[nt][0] = load_px4(brow[nt], pl, pend, true); bv[nt][1] = load_px4(brow[nt], pl + 4, pend, true); }
     }
+  };
+  if (p < pend) load_step(p);
+  for (; p < pend; p += 128) {
+    f32x4 ac[MT][2], bc[NT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { ac[mt][0] = av[mt][0]; ac[mt][1] = av[mt][1]; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { bc[nt][0] = bv[nt][0]; bc[nt][1] = bv[nt][1]; }
+    if (p + 128 < pend) load_step(p + 128);       // prefetch this wave's next 32-pixel step
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -241,19 +276,27 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][h][e], bv[nt][h][e], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt][h][e], bc[nt][h][e], acc[mt][nt], 0, 0, 0);
   }
 
-  float* slab = a.slabs + ((((long)b * gridDim.x + blockIdx.x) * 4 + wave) * (long)a.M) * a.N;
+  // sum the four waves' tiles through LDS, one slab per block
+  constexpr int TILE = MT * NT * 4;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int m = m0 + mt * 16 + j * 4 + reg, n = n0 + nt * 16 + r;
-        if (m < a.M && n < a.N) slab[(long)m * a.N + n] = acc[mt][nt][reg];
-      }
+      for (int reg = 0; reg < 4; ++reg) red[(wave * TILE + (mt * NT + nt) * 4 + reg) * 64 + lane] = acc[mt][nt][reg];
+  __syncthreads();
+  float* slab = a.slabs + (((long)b * gridDim.x + blockIdx.x) * (long)a.M) * a.N;
+  for (int idx = threadIdx.x; idx < TILE * 64; idx += kThreads) {
+    const float v = (red[idx] + red[TILE * 64 + idx]) + (red[2 * TILE * 64 + idx] + red[3 * TILE * 64 + idx]);
+    const int l = idx & 63, q = idx >> 6;
+    const int reg = q & 3, t = q >> 2;
+    const int mt = t / NT, nt = t - mt * NT;
+    const int m = m0 + mt * 16 + (l >> 4) * 4 + reg, n = n0 + nt * 16 + (l & 15);
+    if (m < a.M && n < a.N) slab[(long)m * a.N + n] = v;
+  }
 }
 
 // out[o][m*ld + n] (+)= sum_r slabs[(o*n_red + r)][m*N + n]   -- fixed order => reproducible
@@ -279,7 +322,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_red, 
 template <int MT, int NT>
 int launch_wg(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
   dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnb), (unsigned)B);
-  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), grid, dim3(kThreads), 0, s, a);
+  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -290,7 +333,7 @@ inline int pick_tiles(int dim, int maxt) {   // tiles per block for a dimension 
   return (T + nblk - 1) / nblk;
 }
 
-inline int wgrad_pch(long HW) { return HW >= 16384 ? 2048 : 512; }
+inline int wgrad_pch(long HW) { return HW >= 16384 ? 1024 : 512; }
 
 }  // namespace
 }  // namespace cidnet
@@ -322,7 +365,7 @@ int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_m
 long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW) {
   const int pch = wgrad_pch(HW);
   const long chunks = (HW + pch - 1) / pch;
-  return (long)B * chunks * 4 * M * N;
+  return (long)B * chunks * M * N;
 }
 
 int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld, int per_sample,
@@ -345,7 +388,7 @@ int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, floa
   if (rc != CIDNET_OK) return rc;
   const long ne = (long)M * N;
   dim3 grid((unsigned)((ne + 255) / 256), per_sample ? (unsigned)B : 1u);
-  const int n_red = per_sample ? chunks * 4 : B * chunks * 4;
+  const int n_red = per_sample ? chunks : B * chunks;
   hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, s, ws, n_red, M, N, dW, (long)M * dw_ld, dw_ld, accumulate);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;

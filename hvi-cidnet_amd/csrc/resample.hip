@@ -83,38 +83,55 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, int n, float* _
   if (threadIdx.x == 0) out[0] = s;
 }
 
-// din[pl][yi][xi] = sum over (yo, xo) of wy * wx * dout[pl][yo][xo]
+// Per-dimension adjoint tables: for input index i the (at most kTabK) output indices whose 2-tap
+// footprint contains i, with their weights.  Membership is decided with the forward's own float
+// arithmetic (src_tap), so the adjoint matches the forward exactly.
+constexpr int kTabK = 6;
+
+__global__ void bilinear_tab_kernel(int* __restrict__ idx, float* __restrict__ wgt, int in, int out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in) return;
+  const float s = ac_scale(in, out);
+  const float is = s > 0.f ? 1.f / s : 0.f;
+  int lo = s > 0.f ? (int)floorf((float)(i - 1) * is) - 1 : 0;
+  int hi = s > 0.f ? (int)ceilf((float)(i + 1) * is) + 1 : out - 1;
+  lo = max(lo, 0); hi = min(hi, out - 1);
+  int n = 0;
+  for (int o = lo; o <= hi && n < kTabK; ++o) {
+    const Tap1 t = src_tap(o, s, in);
+    float w = 0.f;
+    if (t.i0 == i) w += 1.f - t.l1;
+    if (t.i1 == i) w += t.l1;
+    if (w != 0.f) { idx[i * kTabK + n] = o; wgt[i * kTabK + n] = w; ++n; }
+  }
+  for (; n < kTabK; ++n) { idx[i * kTabK + n] = 0; wgt[i * kTabK + n] = 0.f; }
+}
+
+// din[pl][yi][xi] = sum over table taps of wy * wx * dout[pl][yo][xo]   (gather: no atomics)
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                const int* __restrict__ yidx, const float* __restrict__ ywgt,
+                                                                const int* __restrict__ xidx, const float* __restrict__ xwgt,
                                                                 long planes, int Hi, int Wi, int Ho, int Wo) {
   const long total = planes * Hi * Wi;
-  const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
-  const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int xi = (int)(i % Wi);
     const int yi = (int)((i / Wi) % Hi);
     const long pl = i / ((long)Wi * Hi);
-    // candidate outputs: scale*o in [i-1, i+1)  (exact membership is re-tested with the forward's arithmetic)
-    int ylo = sh > 0.f ? (int)floorf((float)(yi - 1) * ish) - 1 : 0;
-    int yhi = sh > 0.f ? (int)ceilf((float)(yi + 1) * ish) + 1 : Ho - 1;
-    int xlo = sw > 0.f ? (int)floorf((float)(xi - 1) * isw) - 1 : 0;
-    int xhi = sw > 0.f ? (int)ceilf((float)(xi + 1) * isw) + 1 : Wo - 1;
-    ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, Ho - 1); xhi = min(xhi, Wo - 1);
     const float* g = dout + pl * (long)Ho * Wo;
+    int xo[kTabK];
+    float xw[kTabK];
+#pragma unroll
+    for (int k = 0; k < kTabK; ++k) { xo[k] = xidx[xi * kTabK + k]; xw[k] = xwgt[xi * kTabK + k]; }
     float s = 0.f;
-    for (int yo = ylo; yo <= yhi; ++yo) {
-      const Tap1 ty = src_tap(yo, sh, Hi);
-      float wy = 0.f;
-      if (ty.i0 == yi) wy += 1.f - ty.l1;
-      if (ty.i1 == yi) wy += ty.l1;
+#pragma unroll
+    for (int ky = 0; ky < kTabK; ++ky) {
+      const float wy = ywgt[yi * kTabK + ky];
       if (wy == 0.f) continue;
+      const float* row = g + (long)yidx[yi * kTabK + ky] * Wo;
       float rs = 0.f;
-      for (int xo = xlo; xo <= xhi; ++xo) {
-        const Tap1 tx = src_tap(xo, sw, Wi);
-        float wx = 0.f;
-        if (tx.i0 == xi) wx += 1.f - tx.l1;
-        if (tx.i1 == xi) wx += tx.l1;
-        if (wx != 0.f) rs += wx * g[(long)yo * Wo + xo];
-      }
+#pragma unroll
+      for (int k = 0; k < kTabK; ++k)
+        if (xw[k] != 0.f) rs += xw[k] * row[xo[k]];
       s += wy * rs;
     }
     din[i] = s;
@@ -172,11 +189,24 @@ int cidnet_prelu_bwd(const float* dout, const float* pre, const float* slope, fl
   return CIDNET_OK;
 }
 
-int cidnet_bilinear_bwd(const float* dout, float* din, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
-  CIDNET_CHECK_ARG(dout && din && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+long cidnet_bilinear_bwd_ws_floats(int Hi, int Wi) { return 2L * kTabK * ((long)Hi + Wi); }
+
+int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                        void* stream) {
+  CIDNET_CHECK_ARG(dout && din && ws && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  if (ws_floats < cidnet_bilinear_bwd_ws_floats(Hi, Wi)) return CIDNET_ERR_WS;
+  hipStream_t s = (hipStream_t)stream;
+  int* yidx = reinterpret_cast<int*>(ws);
+  float* ywgt = ws + (long)kTabK * Hi;
+  int* xidx = reinterpret_cast<int*>(ws + 2L * kTabK * Hi);
+  float* xwgt = ws + 2L * kTabK * Hi + (long)kTabK * Wi;
+  hipLaunchKernelGGL(bilinear_tab_kernel, dim3((Hi + 255) / 256), dim3(256), 0, s, yidx, ywgt, Hi, Ho);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(bilinear_tab_kernel, dim3((Wi + 255) / 256), dim3(256), 0, s, xidx, xwgt, Wi, Wo);
+  CIDNET_LAUNCH_STATUS();
   const long planes = (long)B * C;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(planes * Hi * Wi, 16384)), dim3(kThreads), 0, (hipStream_t)stream,
-                     dout, din, planes, Hi, Wi, Ho, Wo);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(planes * Hi * Wi, 16384)), dim3(kThreads), 0, s, dout, din, yidx, ywgt,
+                     xidx, xwgt, planes, Hi, Wi, Ho, Wo);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

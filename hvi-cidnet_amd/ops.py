@@ -193,6 +193,12 @@ def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False):
                N, H, W, _stream())
 
 
+def bilinear_bwd(dout, din, B, C, Hi, Wi, Ho, Wo):
+    n = _raw("cidnet_bilinear_bwd_ws_floats", Hi, Wi)
+    ws = _ws(n, dout.device)
+    lib().call("cidnet_bilinear_bwd", _p(dout), _p(din), _p(ws), ws.numel(), B, C, Hi, Wi, Ho, Wo, _stream())
+
+
 def prelu_bwd(go, pre, slope):
     dpre = torch.empty_like(pre)
     dslope = grad_like(slope)
@@ -402,7 +408,7 @@ class DownFn(torch.autograd.Function):
         go = _c(go)
         dpre, dslope = prelu_bwd(go, pre, slope)
         dt = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
-        lib().call("cidnet_bilinear_bwd", _p(dpre), _p(dt), B, Co, H, W, H // 2, W // 2, _stream())
+        bilinear_bwd(dpre, dt, B, Co, H, W, H // 2, W // 2)
         gw = grad_like(w)
         conv3x3_wgrad(dt, x, gw, B, Co, Ci, H, W)
         dx = None
@@ -452,7 +458,7 @@ class UpFn(torch.autograd.Function):
             dskip = torch.empty_like(skip)
             pw_conv(dpre, 0, Co * HWh, w_up, Co, 0, 1, 2 * Co, dskip, 0, Co * HWh, B, Co, Co, HWh)
         dz = torch.empty_like(t)
-        lib().call("cidnet_bilinear_bwd", _p(dpre), _p(dz), B, Co, h, wd, 2 * h, 2 * wd, _stream())
+        bilinear_bwd(dpre, dz, B, Co, h, wd, 2 * h, 2 * wd)
         pw_wgrad(dz, 0, Co * HWl, t, 0, Co * HWl, g_wup, 0, 2 * Co, B, Co, Co, HWl)
         dt = torch.empty_like(t)
         pw_conv(dz, 0, Co * HWl, w_up, 0, 0, 1, 2 * Co, dt, 0, Co * HWl, B, Co, Co, HWl)

@@ -129,8 +129,9 @@ long cidnet_prelu_bwd_ws_floats(void);
 int cidnet_prelu_bwd(const float* dout, const float* pre, const float* slope, float* dpre,
                      float* dslope, float* ws, long ws_floats, long n, void* stream);
 /* adjoint of bilinear (Hi,Wi)->(Ho,Wo): din (B,C,Hi,Wi) from dout (B,C,Ho,Wo), gather form. */
-int cidnet_bilinear_bwd(const float* dout, float* din, int B, int C, int Hi, int Wi, int Ho, int Wo,
-                        void* stream);
+long cidnet_bilinear_bwd_ws_floats(int Hi, int Wi);
+int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats, int B, int C, int Hi,
+                        int Wi, int Ho, int Wo, void* stream);
 int cidnet_add(const float* a, const float* b, float* y, long n, void* stream);
 
 /* ---- K7: channel attention of CAB  (net/LCA.py:26-38) -------------------------------------------

@@ -137,7 +137,7 @@ def test_bilinear_bwd_and_down(dev, B, C, Hi, Wi, Ho, Wo):
     yr.backward(g)
     din = torch.empty((B, C, Hi, Wi), device=dev)
     gd, xd = g.to(dev), x.to(dev)          # keep the device tensors alive while raw pointers are in flight
-    lib().call("cidnet_bilinear_bwd", ops._p(gd), ops._p(din), B, C, Hi, Wi, Ho, Wo, ops._stream())
+    ops.bilinear_bwd(gd, din, B, C, Hi, Wi, Ho, Wo)
     close(din, xr.grad, what="bilinear adjoint")
     if Ho == Hi // 2 and Wo == Wi // 2:
         slope = torch.tensor([0.17])
