@@ -8,8 +8,9 @@ ROCm device and libcidnet_hip.so must be built (`python hvi-cidnet_amd/build.py`
 """
 from . import _lib  # noqa: F401
 from .cidnet import CIDNet
+from .cidnet_mssa import CIDNet as CIDNet_MSSA, SpatialAttention
 from .hvi_transform import RGB_HVI
 from .lca import CAB, IEL, HV_LCA, I_LCA
 from .transformer_utils import LayerNorm, NormDownsample, NormUpsample
 
-__all__ = ["CIDNet", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample"]
+__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample"]

@@ -72,6 +72,16 @@ class CIDNet(nn.Module, _HubMixin):
 
         self.trans = RGB_HVI()
 
+    # hooks the MSSA variant overrides (net/CIDNet_MSSA.py); identity / dead-block skip for the base net
+    def _gate(self, name, t):
+        return t
+
+    def _i_dec2_input(self, i_dec3, hv_3):
+        # net/CIDNet.py:105 evaluates I_LCA5(i_dec3, hv_3) and :109 then ignores it (ID_block2 is fed
+        # i_dec3): the result never reaches the output and its 13 parameters get no gradient, so the
+        # dead block is not executed here.
+        return i_dec3
+
     def forward(self, x):
         if x.shape[2] % 8 or x.shape[3] % 8:
             raise RuntimeError(f"CIDNet: H and W must be multiples of 8 (got {tuple(x.shape[2:])}); the reference "
@@ -104,22 +114,20 @@ class CIDNet(nn.Module, _HubMixin):
         i_dec4 = self.I_LCA4(i_enc4, hv_4)
         hv_4 = self.HV_LCA4(hv_4, i_enc4)
 
-        hv_3 = self.HVD_block3(hv_4, hv_jump2)
-        i_dec3 = self.ID_block3(i_dec4, v_jump2)
-        # net/CIDNet.py:105 evaluates I_LCA5(i_dec3, hv_3) and :109 then ignores it (ID_block2 is fed
-        # i_dec3): the result never reaches the output and its 13 parameters get no gradient, so the
-        # dead block is not executed here.
+        hv_3 = self._gate("sa_hv3", self.HVD_block3(hv_4, hv_jump2))
+        i_dec3 = self._gate("sa_i3", self.ID_block3(i_dec4, v_jump2))
+        i_dec2 = self._i_dec2_input(i_dec3, hv_3)
         hv_2 = self.HV_LCA5(hv_3, i_dec3)
 
-        hv_2 = self.HVD_block2(hv_2, hv_jump1)
-        i_dec2 = self.ID_block2(i_dec3, v_jump1)
+        hv_2 = self._gate("sa_hv2", self.HVD_block2(hv_2, hv_jump1))
+        i_dec2 = self._gate("sa_i2", self.ID_block2(i_dec2, v_jump1))
 
         i_dec1 = self.I_LCA6(i_dec2, hv_2)
         hv_1 = self.HV_LCA6(hv_2, i_dec2)
 
-        i_dec1 = self.ID_block1(i_dec1, i_jump0)
+        i_dec1 = self._gate("sa_i1", self.ID_block1(i_dec1, i_jump0))
         i_dec0 = self.ID_block0(i_dec1)
-        hv_1 = self.HVD_block1(hv_1, hv_jump0)
+        hv_1 = self._gate("sa_hv1", self.HVD_block1(hv_1, hv_jump0))
         hv_0 = self.HVD_block0(hv_1)
 
         # cat([hv_0, i_dec0], 1) + hvi -> PHVIT, fused (net/CIDNet.py:119-120)

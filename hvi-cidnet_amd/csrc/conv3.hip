@@ -30,6 +30,7 @@ struct C3Args {
   int flip;        // tap' = 8 - tap (data gradient)
   int replicate;   // border mode of the input
   int nmb;         // number of m-blocks (blockIdx.z = b*nmb + mb)
+  int tpb;         // row tiles per block (launcher)
 };
 
 struct Win6 {
@@ -72,30 +73,19 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   constexpr int MB = 16 * MT;
   constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
   constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
+  constexpr int TROWS = 4 * NY * kR;            // output rows of one block tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, j = lane >> 4;
   const int b = blockIdx.z / a.nmb, mb = blockIdx.z - b * a.nmb;
   const int m0 = mb * MB;
   const int x0 = blockIdx.x * (XL * 4) + 4 * (c & (XL - 1));
-  const int yw = blockIdx.y * (4 * NY * kR) + wave * (NY * kR) + (c >> LOGX) * kR;   // first output row of this lane
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
   const float* Xb = a.X + (long)b * a.x_bs;
   const bool rep = a.replicate != 0;
-  const bool wave_live = blockIdx.y * (4 * NY * kR) + wave * (NY * kR) < H;
+  const bool single = a.K <= kKC;               // whole weight panel resident: walk `tpb` row tiles
 
-  f32x4 acc[kR][MT][4];
-#pragma unroll
-  for (int r = 0; r < kR; ++r)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[r][mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int kc0 = 0; kc0 < a.K; kc0 += kKC) {
-    const int kcn = min(kKC, a.K - kc0);
-    const int ng = (kcn + 3) >> 2;
-    __syncthreads();
+  auto stage = [&](int kc0, int kcn, int ng) {
     for (int i = tid; i < ng * 4 * 9 * MB; i += kThreads) {
       const int mm = i % MB;
       const int t = (i / MB) % 9;
@@ -105,78 +95,115 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
         v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
       As[(kk * 9 + t) * ldA + mm] = v;
     }
+  };
+  if (single) {
+    stage(0, a.K, (a.K + 3) >> 2);
     __syncthreads();
-    if (!wave_live) continue;                    // wave-uniform; the wave still joins the barriers above
-    // channels past K are clamped to a valid plane: their weights are zero in LDS
-    Win6 nxt[kR + 2];
-    {
-      const float* plane = Xb + (long)min(kc0 + j, a.K - 1) * HW;
+  }
+
+  const int ntiles = (H + TROWS - 1) / TROWS;
+  const int tile_end = min((int)(blockIdx.y + 1) * a.tpb, ntiles);
+  for (int tile = blockIdx.y * a.tpb; tile < tile_end; ++tile) {
+    const int ywave = tile * TROWS + wave * (NY * kR);
+    const int yw = ywave + (c >> LOGX) * kR;    // first output row of this lane
+    const bool wave_live = ywave < H;
+
+    f32x4 acc[kR][MT][4];
 #pragma unroll
-      for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
-    }
-    for (int g = 0; g < ng; ++g) {
-      Win6 win[kR + 2];
+    for (int r = 0; r < kR; ++r)
 #pragma unroll
-      for (int iy = 0; iy < kR + 2; ++iy) win[iy] = nxt[iy];
-      if (g + 1 < ng) {
-        const float* plane = Xb + (long)min(kc0 + 4 * (g + 1) + j, a.K - 1) * HW;
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < a.K; kc0 += kKC) {
+      const int kcn = min(kKC, a.K - kc0);
+      const int ng = (kcn + 3) >> 2;
+      if (!single) {
+        __syncthreads();
+        stage(kc0, kcn, ng);
+        __syncthreads();
+      }
+      if (!wave_live) continue;                  // wave-uniform; the wave still joins the barriers above
+      // channels past K are clamped to a valid plane: their weights are zero in LDS
+      Win6 nxt[kR + 2];
+      {
+        const float* plane = Xb + (long)min(kc0 + j, a.K - 1) * HW;
 #pragma unroll
         for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
       }
-      float av[9][MT];
+      for (int g = 0; g < ng; ++g) {
+        Win6 win[kR + 2];
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+        for (int iy = 0; iy < kR + 2; ++iy) win[iy] = nxt[iy];
+        if (g + 1 < ng) {
+          const float* plane = Xb + (long)min(kc0 + 4 * (g + 1) + j, a.K - 1) * HW;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[((g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
+          for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+        }
+        float av[9][MT];
 #pragma unroll
-      for (int iy = 0; iy < kR + 2; ++iy)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < kR; ++r) {
-          const int dy = iy - r;
-          if (dy < 0 || dy > 2) continue;
+          for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[((g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
+        for (int iy = 0; iy < kR + 2; ++iy)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+          for (int r = 0; r < kR; ++r) {
+            const int dy = iy - r;
+            if (dy < 0 || dy > 2) continue;
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                acc[r][mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dy * 3 + dx][mt], win[iy].v[e + dx], acc[r][mt][e], 0, 0, 0);
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[r][mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dy * 3 + dx][mt], win[iy].v[e + dx], acc[r][mt][e], 0, 0, 0);
+          }
+      }
+    }
+
+    if (x0 >= W || !wave_live) continue;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int y = yw + r;
+      if (y >= H) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int m = m0 + mt * 16 + j * 4 + reg;
+          if (m >= a.M) continue;
+          float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
+          const f32x4 v = {acc[r][mt][0][reg], acc[r][mt][1][reg], acc[r][mt][2][reg], acc[r][mt][3][reg]};
+          if (x0 + 3 < W) {
+            store4u(row + x0, v);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (x0 + e < W) row[x0 + e] = v[e];
+          }
         }
     }
-  }
-
-  if (x0 >= W) return;
-#pragma unroll
-  for (int r = 0; r < kR; ++r) {
-    const int y = yw + r;
-    if (y >= H) continue;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int m = m0 + mt * 16 + j * 4 + reg;
-        if (m >= a.M) continue;
-        float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
-        const f32x4 v = {acc[r][mt][0][reg], acc[r][mt][1][reg], acc[r][mt][2][reg], acc[r][mt][3][reg]};
-        if (x0 + 3 < W) {
-          store4u(row + x0, v);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (x0 + e < W) row[x0 + e] = v[e];
-        }
-      }
   }
 }
 
 template <int MT, int LOGX>
-int launch_c3x(const C3Args& a, int B, hipStream_t s) {
+int launch_c3x(C3Args a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT;
   constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
   constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
   const int kc = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
   const size_t lds = (size_t)kc * 9 * ldA * sizeof(float);
-  dim3 grid((unsigned)((a.W + XL * 4 - 1) / (XL * 4)), (unsigned)((a.H + 4 * NY * kR - 1) / (4 * NY * kR)), (unsigned)(B * a.nmb));
+  const int xt = (a.W + XL * 4 - 1) / (XL * 4);
+  const int ntiles = (a.H + 4 * NY * kR - 1) / (4 * NY * kR);
+  long tpb = 1;
+  if (a.K <= kKC) {                              // weights stay resident: walk several row tiles per block
+    tpb = (long)xt * ntiles * B * a.nmb / 2048;
+    tpb = tpb < 1 ? 1 : (tpb > 4 ? 4 : tpb);
+  }
+  a.tpb = (int)tpb;
+  dim3 grid((unsigned)xt, (unsigned)((ntiles + tpb - 1) / tpb), (unsigned)(B * a.nmb));
   hipLaunchKernelGGL((conv3_kernel<MT, LOGX>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
@@ -344,14 +371,17 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
   }
 }
 
-__global__ void c3_reduce_kernel(const float* __restrict__ slabs, int n_red, long ne, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne) return;
-  float t0 = 0.f, t1 = 0.f;
-  int k = 0;
-  for (; k + 1 < n_red; k += 2) { t0 += slabs[(long)k * ne + i]; t1 += slabs[(long)(k + 1) * ne + i]; }
-  if (k < n_red) t0 += slabs[(long)k * ne + i];
-  out[i] = t0 + t1;
+__global__ __launch_bounds__(256) void c3_reduce_kernel(const float* __restrict__ slabs, int n_red, long ne, float* __restrict__ out) {
+  __shared__ float part[8][33];
+  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + ex;
+  float t = 0.f;
+  if (i < ne)
+    for (int k = sl; k < n_red; k += 8) t += slabs[(long)k * ne + i];
+  part[sl][ex] = t;
+  __syncthreads();
+  if (sl == 0 && i < ne)
+    out[i] = ((part[0][ex] + part[1][ex]) + (part[2][ex] + part[3][ex])) + ((part[4][ex] + part[5][ex]) + (part[6][ex] + part[7][ex]));
 }
 
 // rows per chunk: enough blocks to fill the chip (>= ~1024) without going below 16 rows per block
@@ -458,7 +488,7 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
   else hipLaunchKernelGGL((conv3_wgrad_kernel<3>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   const long ne = (long)M * N * 9;
-  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, ws, B * chunks, ne, dW);
+  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, s, ws, B * chunks, ne, dW);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

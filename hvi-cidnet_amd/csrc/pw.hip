@@ -20,7 +20,8 @@ namespace cidnet {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kKC = 128;   // K rows staged per chunk
+constexpr int kDepth = 4;     // k-steps of the activation operand prefetched per wave
+int g_pw_dbg = 0;             // timing-study switches (cidnet_debug_pw_flags): 1 no stores, 2 no K loop, 4 LDS kernel only
 
 struct PwArgs {
   const float* X; long x_bs;
@@ -31,6 +32,8 @@ struct PwArgs {
   const float* slope;
   float* Ypre;
   int M, K; long HW; int W;
+  int kc, tpb, tile0, ntile_lim;   // K rows per LDS chunk; tiles per block; first tile; end tile (launcher)
+  int dbg;              // ablation switches for kernel timing studies (0 in production)
 };
 
 __device__ __forceinline__ f32x4 load_px4(const float* row, long p, long HW, bool valid) {
@@ -77,7 +80,12 @@ __device__ __forceinline__ UpTap up_tap(long p, int W, int zh, int zw) {
 }
 
 // EPI: 0 plain, 1 + residual R, 2 + bilinear_x2(Z) then PReLU (writes optional pre-activation)
-template <int MT, int EPI>
+// A block stages its weight panel in LDS once (when all of K fits: `single`) and then walks `tpb`
+// consecutive 256-pixel tiles.  TAIL = false is the streaming kernel: it requires HW % 4 == 0, so
+// every lane's 4 pixels are all inside or all outside the plane; outside lanes load a clamped
+// (valid) address and store nothing, hence no bounds code in the loop.  TAIL = true is the fully
+// checked variant, launched only for the last tile of planes with HW % 4 != 0.
+template <int MT, int EPI, bool TAIL>
 __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   extern __shared__ float As[];
   constexpr int MB = 16 * MT;
@@ -86,112 +94,333 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   const int c = lane & 15, j = lane >> 4;
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * MB;
-  const long p0 = (long)blockIdx.x * 256 + wave * 64 + 4 * c;
   const long HW = a.HW;
   const float* Xb = a.X + (long)b * a.x_bs;
   const float* Wb = a.Wt + (long)b * a.w_bs;
-  const bool full = (long)blockIdx.x * 256 + 256 <= HW;      // block-uniform
+  const int kcmax = a.kc;
+  const bool single = a.K <= kcmax;
+  const long tile_beg = a.tile0 + (long)blockIdx.x * a.tpb;
+  const long tile_end = min(tile_beg + a.tpb, (long)a.ntile_lim);
 
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int kc0 = 0; kc0 < a.K; kc0 += kKC) {
-    const int kcn = min(kKC, a.K - kc0);
-    const int kcn4 = (kcn + 3) & ~3;
-    __syncthreads();
+  auto stage = [&](int kc0, int kcn, int kcn4) {
     for (int i = tid; i < kcn4 * MB; i += kThreads) {
       const int kk = i / MB, mm = i - kk * MB;
       float v = 0.f;
       if (kk < kcn && m0 + mm < a.M) v = Wb[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks];
       As[kk * ldA + mm] = v;
     }
+  };
+  if (single) {
+    stage(0, a.K, (a.K + 3) & ~3);
     __syncthreads();
-    // Rows past K are clamped to a valid row: their A entries are zero-padded in LDS, so no
-    // predicate is needed; only the last pixel block of a plane takes the bounds-checked loads.
-    const int klast = kcn - 1;
-    if (full) {
-      const float* xp = Xb + (long)kc0 * HW + p0;
-      f32x4 xv = load4u(xp + (long)min(j, klast) * HW);
-      for (int k4 = 0; k4 < kcn4; k4 += 4) {
-        const f32x4 xc = xv;
-        if (k4 + 4 < kcn4) xv = load4u(xp + (long)min(k4 + 4 + j, klast) * HW);
+  }
+
+  for (long tile = tile_beg; tile < tile_end; ++tile) {
+    const long p0 = tile * 256 + wave * 64 + 4 * c;
+    const long pld = TAIL ? p0 : (p0 < HW - 4 ? p0 : HW - 4);     // clamped load position (streaming kernel)
+    f32x4 acc[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float av = As[(k4 + j) * ldA + mt * 16 + c];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
-        }
+      for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < ((a.dbg & 2) ? 0 : a.K); kc0 += kcmax) {
+      const int kcn = min(kcmax, a.K - kc0);
+      const int kcn4 = (kcn + 3) & ~3;
+      if (!single) {
+        __syncthreads();
+        stage(kc0, kcn, kcn4);
+        __syncthreads();
       }
-    } else {
-      f32x4 xv = load_px4(Xb + (long)(kc0 + j) * HW, p0, HW, j < kcn);
-      for (int k4 = 0; k4 < kcn4; k4 += 4) {
-        const f32x4 xc = xv;
-        if (k4 + 4 < kcn4) xv = load_px4(Xb + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn);
+      // Rows past K are clamped to a valid row: their A entries are zero-padded in LDS.
+      const int klast = kcn - 1;
+      if (!TAIL) {
+        // kDepth k-steps of X stay in flight per wave (HBM latency >> the MFMA time of one k-step)
+        const float* xp = Xb + (long)kc0 * HW + pld;
+        f32x4 ring[kDepth];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float av = As[(k4 + j) * ldA + mt * 16 + c];
+        for (int d = 0; d < kDepth; ++d) ring[d] = load4u(xp + (long)min(4 * d + j, klast) * HW);
+#pragma unroll 1
+        for (int kb = 0; kb < kcn4; kb += 4 * kDepth) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+          for (int d = 0; d < kDepth; ++d) {        // static ring slots: no register rotation, counted vmcnt
+            const int k4 = kb + 4 * d;
+            if (k4 >= kcn4) break;
+            const f32x4 xc = ring[d];
+            ring[d] = load4u(xp + (long)min(k4 + 4 * kDepth + j, klast) * HW);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const float av = As[(k4 + j) * ldA + mt * 16 + c];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        f32x4 xv = load_px4(Xb + (long)(kc0 + j) * HW, p0, HW, j < kcn);
+        for (int k4 = 0; k4 < kcn4; k4 += 4) {
+          const f32x4 xc = xv;
+          if (k4 + 4 < kcn4) xv = load_px4(Xb + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float av = As[(k4 + j) * ldA + mt * 16 + c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[e], acc[mt][e], 0, 0, 0);
+          }
         }
       }
     }
-  }
 
-  if (p0 >= HW) return;
-  UpTap tap[4];
-  float slope = 0.f;
-  if (EPI == 2) {
-    slope = a.slope[0];
+    if (p0 >= HW) continue;
+    if (a.dbg & 1) {                      // ablation: keep the accumulators alive, store nothing
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tap[e] = up_tap(p0 + e < HW ? p0 + e : HW - 1, a.W, a.zh, a.zw);
-  }
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+        for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[mt][e]));
+      continue;
+    }
+    UpTap tap[4];
+    float slope = 0.f;
+    if (EPI == 2) {
+      slope = a.slope[0];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int m = m0 + mt * 16 + j * 4 + reg;
-      if (m >= a.M) continue;
-      f32x4 v = {acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
-      if (EPI == 1) v += load_px4(a.R + (long)b * a.r_bs + (long)m * HW, p0, HW, true);
-      if (EPI == 2) {
-        const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
+      for (int e = 0; e < 4; ++e) tap[e] = up_tap(p0 + e < HW ? p0 + e : HW - 1, a.W, a.zh, a.zw);
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const UpTap& t = tap[e];
-          const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
-          const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
-          v[e] += (1.f - t.ly) * top + t.ly * bot;
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + mt * 16 + j * 4 + reg;
+        if (m >= a.M) continue;
+        f32x4 v = {acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
+        if (EPI == 1) {
+          const float* rrow = a.R + (long)b * a.r_bs + (long)m * HW;
+          v += TAIL ? load_px4(rrow, p0, HW, true) : load4u(rrow + p0);
         }
-        if (a.Ypre) store_px4(a.Ypre + (long)b * a.y_bs + (long)m * HW, p0, HW, v);
+        if (EPI == 2) {
+          const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+          for (int e = 0; e < 4; ++e) {
+            const UpTap& t = tap[e];
+            const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
+            const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
+            v[e] += (1.f - t.ly) * top + t.ly * bot;
+          }
+          if (a.Ypre) {
+            float* prow = a.Ypre + (long)b * a.y_bs + (long)m * HW;
+            if (TAIL) store_px4(prow, p0, HW, v); else store4u(prow + p0, v);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+        }
+        float* yrow = a.Y + (long)b * a.y_bs + (long)m * HW;
+        if (TAIL) store_px4(yrow, p0, HW, v); else store4u(yrow + p0, v);
       }
-      store_px4(a.Y + (long)b * a.y_bs + (long)m * HW, p0, HW, v);
+      // keep the scheduler from hoisting every accumulator read-out above the first store
+      // (it would cost 16*MT extra VGPRs and halve the occupancy)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-template <int MT>
-int launch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
+// Register-resident weights: for small K (<= 4*KS) the whole A panel of a block (KS x MT
+// fragments) lives in VGPRs, so the kernel has no LDS, no barrier and no per-k-step LDS latency; a
+// block walks `tpb` pixel tiles and prefetches the next tile's first k-steps before it stores.
+// Requires HW % 4 == 0 (streaming addressing, see pw_conv_kernel) -- the ragged tail tile of other
+// planes goes through pw_conv_kernel<.., TAIL = true>.
+template <int MT, int EPI, int KS>
+__global__ __launch_bounds__(kThreads) void pw_conv_rega_kernel(PwArgs a) {
   constexpr int MB = 16 * MT;
-  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
-  const int kc = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
-  const size_t lds = (size_t)kc * ldA * sizeof(float);
-  dim3 grid((unsigned)((a.HW + 255) / 256), (unsigned)((a.M + MB - 1) / MB), (unsigned)B);
-  if (epi == 0) hipLaunchKernelGGL((pw_conv_kernel<MT, 0>), grid, dim3(kThreads), lds, s, a);
-  else if (epi == 1) hipLaunchKernelGGL((pw_conv_kernel<MT, 1>), grid, dim3(kThreads), lds, s, a);
-  else hipLaunchKernelGGL((pw_conv_kernel<MT, 2>), grid, dim3(kThreads), lds, s, a);
+  constexpr int D = kDepth;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, j = lane >> 4;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * MB;
+  const long HW = a.HW;
+  const float* Xb = a.X + (long)b * a.x_bs;
+  const float* Wb = a.Wt + (long)b * a.w_bs;
+  const long tile_beg = (long)blockIdx.x * a.tpb;
+  const long tile_end = min(tile_beg + a.tpb, (long)a.ntile_lim);
+  const int klast = a.K - 1;
+
+  float areg[KS][MT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + c, k = 4 * ks + j;
+      areg[ks][mt] = (m < a.M && k < a.K) ? Wb[(long)m * a.w_ms + (long)k * a.w_ks] : 0.f;
+    }
+
+  auto xrow = [&](long tile, int ks) -> const float* {
+    const long p0 = tile * 256 + wave * 64 + 4 * c;
+    const long pld = p0 < HW - 4 ? p0 : HW - 4;
+    return Xb + (long)min(4 * ks + j, klast) * HW + pld;
+  };
+  f32x4 ring[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < KS) ring[d] = load4u(xrow(tile_beg, d));
+
+  for (long tile = tile_beg; tile < tile_end; ++tile) {
+    const long p0 = tile * 256 + wave * 64 + 4 * c;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 xc = ring[ks % D];
+      if (ks + D < KS) ring[ks % D] = load4u(xrow(tile, ks + D));
+      else if (tile + 1 < tile_end) ring[ks % D] = load4u(xrow(tile + 1, ks + D - KS));   // next tile's head
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks][mt], xc[e], acc[mt][e], 0, 0, 0);
+    }
+
+    if (p0 >= HW) continue;
+    if (a.dbg & 1) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[mt][e]));
+      continue;
+    }
+    UpTap tap[4];
+    float slope = 0.f;
+    if (EPI == 2) {
+      slope = a.slope[0];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tap[e] = up_tap(p0 + e, a.W, a.zh, a.zw);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + mt * 16 + j * 4 + reg;
+        if (m >= a.M) continue;
+        f32x4 v = {acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
+        if (EPI == 1) v += load4u(a.R + (long)b * a.r_bs + (long)m * HW + p0);
+        if (EPI == 2) {
+          const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const UpTap& t = tap[e];
+            const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
+            const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
+            v[e] += (1.f - t.ly) * top + t.ly * bot;
+          }
+          if (a.Ypre) store4u(a.Ypre + (long)b * a.y_bs + (long)m * HW + p0, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+        }
+        store4u(a.Y + (long)b * a.y_bs + (long)m * HW + p0, v);
+      }
+    }
+  }
+}
+
+template <int MT, int EPI, int KS>
+int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
+  constexpr int MB = 16 * MT;
+  const long mblocks = (a.M + MB - 1) / MB;
+  long tpb = nstream * mblocks * B / 2048;
+  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  a.tpb = (int)tpb;
+  a.tile0 = 0;
+  a.ntile_lim = (int)nstream;
+  dim3 grid((unsigned)((nstream + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
+  hipLaunchKernelGGL((pw_conv_rega_kernel<MT, EPI, KS>), grid, dim3(kThreads), 0, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
-int dispatch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
+// -> true if a register-resident instantiation exists for (MT, K); launches it.  Register budget
+// (2 waves/SIMD): MT <= 4 with 9 k-steps, MT <= 3 with 18 or 24.
+template <int MT, int EPI>
+bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
+  const int ks = (a.K + 3) / 4;
+  if constexpr (MT <= 4) {
+    if (ks <= 9) { *rc = launch_pw_rega<MT, EPI, 9>(a, B, nstream, s); return true; }
+  }
+  if constexpr (MT <= 3) {
+    if (ks <= 18) { *rc = launch_pw_rega<MT, EPI, 18>(a, B, nstream, s); return true; }
+    if (ks <= 24) { *rc = launch_pw_rega<MT, EPI, 24>(a, B, nstream, s); return true; }
+  }
+  return false;
+}
+
+template <int MT, int EPI>
+int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
+  constexpr int MB = 16 * MT;
+  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  const int kcmax = ((60 * 1024) / (ldA * 4)) & ~3;          // K rows that fit 60 KB of LDS
+  const int k4 = (a.K + 3) & ~3;
+  a.kc = k4 <= kcmax ? k4 : kcmax;
+  const size_t lds = (size_t)a.kc * ldA * sizeof(float);
+  const long ntiles = (a.HW + 255) / 256;
+  const long mblocks = (a.M + MB - 1) / MB;
+  const bool ragged = (a.HW % 4) != 0 || a.HW < 4;           // last tile needs the checked kernel
+  const long nstream = ragged ? ntiles - 1 : ntiles;
+  bool nstream_done = false;
+  if (nstream > 0 && !(g_pw_dbg & 4)) {
+    int rc = CIDNET_OK;
+    if (try_rega<MT, EPI>(a, B, nstream, s, &rc)) {
+      if (rc != CIDNET_OK) return rc;
+      nstream_done = true;
+    }
+  }
+  if (nstream > 0 && !nstream_done) {
+    long tpb = 1;
+    if (a.K <= a.kc) {                                       // weights stay resident: walk several tiles
+      tpb = nstream * mblocks * B / 4096;
+      tpb = tpb < 1 ? 1 : (tpb > 4 ? 4 : tpb);
+    }
+    a.tpb = (int)tpb;
+    a.tile0 = 0;
+    a.ntile_lim = (int)nstream;
+    dim3 grid((unsigned)((nstream + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
+    hipLaunchKernelGGL((pw_conv_kernel<MT, EPI, false>), grid, dim3(kThreads), lds, s, a);
+    CIDNET_LAUNCH_STATUS();
+  }
+  if (ragged) {
+    a.tpb = 1;
+    a.tile0 = (int)(ntiles - 1);
+    a.ntile_lim = (int)ntiles;
+    dim3 grid(1u, (unsigned)mblocks, (unsigned)B);
+    hipLaunchKernelGGL((pw_conv_kernel<MT, EPI, true>), grid, dim3(kThreads), lds, s, a);
+    CIDNET_LAUNCH_STATUS();
+  }
+  return CIDNET_OK;
+}
+
+template <int MT>
+int launch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
+  if (epi == 0) return launch_pw_epi<MT, 0>(a, B, s);
+  if (epi == 1) return launch_pw_epi<MT, 1>(a, B, s);
+  return launch_pw_epi<MT, 2>(a, B, s);
+}
+
+int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
+  a.dbg = g_pw_dbg;
   const int T = (a.M + 15) / 16;
-  const int nblk = (T + 5) / 6;
-  const int MT = (T + nblk - 1) / nblk;
+  const int ks = (a.K + 3) / 4;
+  int MT;
+  if (ks <= 24 && !(g_pw_dbg & 4)) {
+    // register-resident weights: at most 4 (ks <= 9) or 3 channel tiles per block; fewest padded tiles wins
+    const int mtmax = ks <= 9 ? 4 : 3;
+    int best = 1, best_pad = 1 << 30;
+    for (int mt = mtmax; mt >= 1; --mt) {
+      const int pad = ((T + mt - 1) / mt) * mt;
+      if (pad < best_pad) { best_pad = pad; best = mt; }
+    }
+    MT = best;
+  } else {
+    const int nblk = (T + 5) / 6;
+    MT = (T + nblk - 1) / nblk;
+  }
   switch (MT) {
     case 1: return launch_pw<1>(a, epi, B, s);
     case 2: return launch_pw<2>(a, epi, B, s);
@@ -299,24 +528,28 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   }
 }
 
-// out[o][m*ld + n] (+)= sum_r slabs[(o*n_red + r)][m*N + n]   -- fixed order => reproducible
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_red, int M, int N, float* __restrict__ out,
-                                    long out_os, long out_ld, int accumulate) {
+// out[o][m*ld + n] (+)= sum_r slabs[(o*n_red + r)][m*N + n].  A block reduces 32 elements with 8 lanes
+// each striding over the slabs, then folds the 8 partials through LDS in a fixed order (reproducible).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_red, int M, int N,
+                                                           float* __restrict__ out, long out_os, long out_ld, int accumulate) {
+  __shared__ float part[8][33];
   const long ne = (long)M * N;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ne) return;
+  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + ex;
   const int o = blockIdx.y;
-  const float* s = slabs + (long)o * n_red * ne + i;
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-  int rr = 0;
-  for (; rr + 3 < n_red; rr += 4) {
-    t0 += s[(long)rr * ne]; t1 += s[(long)(rr + 1) * ne]; t2 += s[(long)(rr + 2) * ne]; t3 += s[(long)(rr + 3) * ne];
+  float t = 0.f;
+  if (i < ne) {
+    const float* s = slabs + (long)o * n_red * ne + i;
+    for (int rr = sl; rr < n_red; rr += 8) t += s[(long)rr * ne];
   }
-  for (; rr < n_red; ++rr) t0 += s[(long)rr * ne];
-  const int m = (int)(i / N), n = (int)(i - (long)m * N);
-  float* dst = out + (long)o * out_os + (long)m * out_ld + n;
-  const float v = (t0 + t1) + (t2 + t3);
-  *dst = accumulate ? *dst + v : v;
+  part[sl][ex] = t;
+  __syncthreads();
+  if (sl == 0 && i < ne) {
+    const float v = ((part[0][ex] + part[1][ex]) + (part[2][ex] + part[3][ex])) + ((part[4][ex] + part[5][ex]) + (part[6][ex] + part[7][ex]));
+    const int m = (int)(i / N), n = (int)(i - (long)m * N);
+    float* dst = out + (long)o * out_os + (long)m * out_ld + n;
+    *dst = accumulate ? *dst + v : v;
+  }
 }
 
 template <int MT, int NT>
@@ -341,6 +574,8 @@ inline int wgrad_pch(long HW) { return HW >= 16384 ? 1024 : 512; }
 using namespace cidnet;
 
 extern "C" {
+
+void cidnet_debug_pw_flags(int flags) { g_pw_dbg = flags; }
 
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
                    const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {
@@ -387,7 +622,7 @@ int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, floa
 #undef WG_CASE
   if (rc != CIDNET_OK) return rc;
   const long ne = (long)M * N;
-  dim3 grid((unsigned)((ne + 255) / 256), per_sample ? (unsigned)B : 1u);
+  dim3 grid((unsigned)((ne + 31) / 32), per_sample ? (unsigned)B : 1u);
   const int n_red = per_sample ? chunks : B * chunks;
   hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, s, ws, n_red, M, N, dW, (long)M * dw_ld, dw_ld, accumulate);
   CIDNET_LAUNCH_STATUS();

@@ -501,6 +501,39 @@ class RepConv3x3Fn(torch.autograd.Function):
         return dx, gw
 
 
+class SpatialAttentionFn(torch.autograd.Function):
+    """Reference: SpatialAttention.forward of the MSSA variant, net/CIDNet_MSSA.py:20-25."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _check(x, w)
+        x = _c(x)
+        B, C, H, W = x.shape
+        if tuple(w.shape) != (1, 2, 7, 7):
+            raise RuntimeError("SpatialAttention: only the 7x7 kernel of CIDNet_MSSA is implemented")
+        dev = x.device
+        stats = torch.empty((B, 2, H, W), device=dev, dtype=torch.float32)
+        amax = torch.empty((B, H, W), device=dev, dtype=torch.int32)
+        att = torch.empty((B, 1, H, W), device=dev, dtype=torch.float32)
+        out = torch.empty_like(x)
+        lib().call("cidnet_sa_fwd", _p(x), _p(w), _p(stats), _p(amax), _p(att), _p(out), B, C, H, W, _stream())
+        ctx.save_for_backward(x, w, stats, amax, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, stats, amax, att = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = _c(g)
+        gx = torch.empty_like(x)
+        gw = grad_like(w)
+        n = _raw("cidnet_sa_bwd_ws_floats", B, H, W)
+        ws = _ws(n, x.device)
+        lib().call("cidnet_sa_bwd", _p(x), _p(w), _p(stats), _p(amax), _p(att), _p(g), _p(gx), _p(gw), _p(ws), ws.numel(), B, C,
+                   H, W, _stream())
+        return gx, gw
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -77,6 +77,8 @@ int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const
  *   A_b[m][k] = Wt[b*w_bs + m*w_ms + k*w_ks]   (w_bs = 0: shared weights; forward: w_ms=K,w_ks=1;
  *   data gradient: w_ms=1, w_ks=<Cin>), X[b] at X + b*x_bs with channel stride HW (same for Y, R),
  *   so channel slices of wider tensors can be read / written in place.  R may alias Y. */
+/* timing-study switches for cidnet_pw_conv (bit0: no stores, bit1: no K loop); 0 = production */
+void cidnet_debug_pw_flags(int flags);
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
                    float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
                    void* stream);
@@ -160,6 +162,16 @@ int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, 
 int cidnet_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, float grad_scale,
                      void* stream);
+
+/* ---- K13: SpatialAttention of the MSSA variant (net/CIDNet_MSSA.py:10-25) ------------------------
+ * out = x * sigmoid(conv7x7([mean_c x, max_c x])), w: (1,2,7,7).  stats (B,2,H,W), amax (B,H,W int32)
+ * and att (B,1,H,W) are saved for the backward. */
+int cidnet_sa_fwd(const float* x, const float* w, float* stats, int* amax, float* att, float* out,
+                  int B, int C, int H, int W, void* stream);
+long cidnet_sa_bwd_ws_floats(int B, int H, int W);
+int cidnet_sa_bwd(const float* x, const float* w, const float* stats, const int* amax,
+                  const float* att, const float* g, float* gx, float* gw, float* ws, long ws_floats,
+                  int B, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -218,14 +218,26 @@ def i_lca(x, y, p: Params, pre: str, heads: int):
     return x + iel(layernorm_cf(x, nw, nb), p, pre + ".gdfn")
 
 
+def spatial_attention(x, w):
+    """`SpatialAttention.forward` of the MSSA variant, net/CIDNet_MSSA.py:20-25:
+    x * sigmoid(conv7x7([mean_c(x), max_c(x)])), zero pad 3, no bias."""
+    avg = torch.mean(x, dim=1, keepdim=True)
+    mx, _ = torch.max(x, dim=1, keepdim=True)
+    y = F.conv2d(torch.cat([avg, mx], dim=1), w, padding=w.shape[-1] // 2)
+    return x * torch.sigmoid(y)
+
+
 # --------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------
 def cidnet_forward(p: Params, x: torch.Tensor, heads=(1, 2, 4, 8), this_k: Optional[float] = None,
-                   gated=False, alpha_s=1.3, gated2=False, alpha=1.0, taps: Optional[dict] = None):
+                   gated=False, alpha_s=1.3, gated2=False, alpha=1.0, taps: Optional[dict] = None,
+                   variant: str = "base"):
     """`CIDNet.forward`, net/CIDNet.py:71-122, including its two wiring quirks: level-3 encoders
     consume the PRE-LCA2 tensors (:94-95) and ID_block2 consumes i_dec3, so I_LCA5's result is
-    dead (:105,109).  `this_k` defaults to the current value of density_k, which is what the
+    dead (:105,109).  variant="mssa" restates net/CIDNet_MSSA.py:100-159 instead: a SpatialAttention
+    gate after every up block (:133,135,142,144,150,153) and ID_block2 fed by I_LCA5's output (:143),
+    so I_LCA5 is live there.  `this_k` defaults to the current value of density_k, which is what the
     reference's HVIT side effect (HVI_transform.py:38) leaves for PHVIT.  `taps`, if given,
     receives named intermediate activations (for per-stage parity tests)."""
     _, h2, h3, h4 = heads
@@ -256,20 +268,23 @@ def cidnet_forward(p: Params, x: torch.Tensor, heads=(1, 2, 4, 8), this_k: Optio
     i_dec4 = i_lca(i_enc4, hv_4, p, "I_LCA4", h4)
     hv_4 = hv_lca(hv_4, i_enc4, p, "HV_LCA4", h4)
 
-    hv_3 = norm_upsample(hv_4, hv_jump2, p, "HVD_block3")
-    i_dec3 = norm_upsample(i_dec4, v_jump2, p, "ID_block3")
-    # I_LCA5(i_dec3, hv_3) is computed and discarded by the reference (:105); skipped here.
+    mssa = variant == "mssa"
+    sa = (lambda t, name: spatial_attention(t, p[name + ".conv1.weight"])) if mssa else (lambda t, name: t)
+    hv_3 = sa(norm_upsample(hv_4, hv_jump2, p, "HVD_block3"), "sa_hv3")
+    i_dec3 = sa(norm_upsample(i_dec4, v_jump2, p, "ID_block3"), "sa_i3")
+    # base: I_LCA5(i_dec3, hv_3) is computed and discarded by the reference (:105); skipped here.
+    i_dec2_in = i_lca(i_dec3, hv_3, p, "I_LCA5", h3) if mssa else i_dec3
     hv_2 = hv_lca(hv_3, i_dec3, p, "HV_LCA5", h3)
 
-    hv_2 = norm_upsample(hv_2, hv_jump1, p, "HVD_block2")
-    i_dec2 = norm_upsample(i_dec3, v_jump1, p, "ID_block2")  # quirk 2: i_dec3, not I_LCA5 out
+    hv_2 = sa(norm_upsample(hv_2, hv_jump1, p, "HVD_block2"), "sa_hv2")
+    i_dec2 = sa(norm_upsample(i_dec2_in, v_jump1, p, "ID_block2"), "sa_i2")  # base quirk 2: i_dec3 goes in
 
     i_dec1 = i_lca(i_dec2, hv_2, p, "I_LCA6", h2)
     hv_1 = hv_lca(hv_2, i_dec2, p, "HV_LCA6", h2)
 
-    i_dec1 = norm_upsample(i_dec1, i_jump0, p, "ID_block1")
+    i_dec1 = sa(norm_upsample(i_dec1, i_jump0, p, "ID_block1"), "sa_i1")
     i_dec0 = rep_conv3x3(i_dec1, p["ID_block0.1.weight"])
-    hv_1 = norm_upsample(hv_1, hv_jump0, p, "HVD_block1")
+    hv_1 = sa(norm_upsample(hv_1, hv_jump0, p, "HVD_block1"), "sa_hv1")
     hv_0 = rep_conv3x3(hv_1, p["HVD_block0.1.weight"])
 
     out_hvi = torch.cat([hv_0, i_dec0], dim=1) + hvi
@@ -284,9 +299,10 @@ def cidnet_forward(p: Params, x: torch.Tensor, heads=(1, 2, 4, 8), this_k: Optio
 # --------------------------------------------------------------------------------------
 # deterministic, torch-RNG-independent parameters
 # --------------------------------------------------------------------------------------
-def param_shapes(channels=(36, 36, 72, 144), heads=(1, 2, 4, 8)) -> Dict[str, Tuple[int, ...]]:
+def param_shapes(channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), variant: str = "base") -> Dict[str, Tuple[int, ...]]:
     """Names and shapes of the reference's 191 state_dict tensors (net/CIDNet.py:17-69),
-    in the reference's registration order."""
+    in the reference's registration order; variant="mssa" appends the six SpatialAttention convs
+    (net/CIDNet_MSSA.py:91-97) for 197 tensors."""
     c1, c2, c3, c4 = channels
     _, h2, h3, h4 = heads
     s: Dict[str, Tuple[int, ...]] = {}
@@ -341,6 +357,9 @@ def param_shapes(channels=(36, 36, 72, 144), heads=(1, 2, 4, 8)) -> Dict[str, Tu
     for n, (d, nh) in enumerate([(c2, h2), (c3, h3), (c4, h4), (c4, h4), (c3, h3), (c2, h2)], 1):
         i_lca_(f"I_LCA{n}", d, nh)
     s["trans.density_k"] = (1,)
+    if variant == "mssa":
+        for n in ("sa_hv3", "sa_i3", "sa_hv2", "sa_i2", "sa_hv1", "sa_i1"):
+            s[n + ".conv1.weight"] = (1, 2, 7, 7)
     return s
 
 
@@ -352,7 +371,7 @@ def _key_seed(seed: int, key: str) -> int:
 
 
 def make_params(seed: int = 0, channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), jitter: bool = True,
-                dtype=torch.float32) -> Params:
+                dtype=torch.float32, variant: str = "base") -> Params:
     """Counter-based deterministic parameters w = f(seed, key, shape) from numpy's PCG64 (stable
     across numpy/torch versions).  Conv weights ~ U(+-1/sqrt(fan_in)) (PyTorch's default
     Kaiming-uniform a=sqrt(5) bound).  With `jitter` the unit/zero-initialised tensors (LayerNorm
@@ -360,7 +379,7 @@ def make_params(seed: int = 0, channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), j
     parameter; without it they take the reference's init values (1/0, 0.25, 1, 0.2)."""
     import numpy as np
     out: Params = {}
-    for key, shape in param_shapes(channels, heads).items():
+    for key, shape in param_shapes(channels, heads, variant).items():
         rng = np.random.Generator(np.random.PCG64(_key_seed(seed, key)))
         u = rng.random(shape, dtype=np.float64) * 2.0 - 1.0
         if key.endswith("norm.weight"):

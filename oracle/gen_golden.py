@@ -310,9 +310,60 @@ def gen_model():
     print("wrote model.npz", len(out), "arrays")
 
 
+def gen_mssa():
+    """MSSA variant (net/CIDNet_MSSA.py): SpatialAttention block + whole model, reduced width, all gradients."""
+    from net.CIDNet_MSSA import CIDNet as RefMSSA, SpatialAttention as RefSA
+    out = {}
+    sa = RefSA()
+    w = O.make_params(7, channels=(12, 12, 24, 48), variant="mssa")["sa_hv3.conv1.weight"] * 4.0
+    sa.load_state_dict({"conv1.weight": w})
+    x = O.synthetic_batch(71, (2, 12, 20, 28)) - 0.3
+    x[0, :, 3, 4] = x[0, 0, 3, 4]                        # a pixel whose channels all tie (arg-max = channel 0)
+    xr = x.clone().requires_grad_(True)
+    yr = sa(xr)
+    gy = O.synthetic_batch(72, tuple(yr.shape)) - 0.5
+    yr.backward(gy)
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = O.spatial_attention(xo, wo)
+    yo.backward(gy)
+    check_equal(yo, yr, "SpatialAttention fwd")
+    check_equal(xo.grad, xr.grad, "SpatialAttention dx", exact=False, tol=1e-6)
+    check_equal(wo.grad, sa.conv1.weight.grad, "SpatialAttention dw", exact=False, tol=1e-5)
+    out.update(sa_x=x.numpy(), sa_w=w.numpy(), sa_out=yr.detach().numpy(), sa_gout=gy.numpy(), sa_gx=xr.grad.numpy(),
+               sa_gw=sa.conv1.weight.grad.numpy())
+    chans = (12, 12, 24, 48)
+    p = O.make_params(5, channels=chans, variant="mssa")
+    m = RefMSSA(channels=list(chans))
+    load_into(m, p)
+    assert len(m.state_dict()) == 197
+    x = O.synthetic_batch(51, (2, 3, 32, 48))
+    gt = O.synthetic_batch(52, (2, 3, 32, 48))
+    yr = m(x)
+    (yr - gt).abs().mean().backward()
+    po = O.params_to(p, requires_grad=True)
+    yo = O.cidnet_forward(po, x, variant="mssa")
+    (yo - gt).abs().mean().backward()
+    check_equal(yo, yr, "CIDNet_MSSA fwd")
+    out.update(model_x=x.numpy(), model_gt=gt.numpy(), model_out=yr.detach().numpy())
+    worst = 0.0
+    for n, prm in m.named_parameters():
+        assert prm.grad is not None, n                  # I_LCA5 is live in this variant
+        d = (prm.grad - po[n].grad).abs().max().item() / max(prm.grad.abs().max().item(), 1e-30)
+        worst = max(worst, d)
+        out[f"model_g.{n}"] = prm.grad.numpy()
+    print(f"  ok  CIDNet_MSSA grads: worst rel-to-max diff oracle vs reference {worst:.2e}")
+    assert worst < 1e-4
+    np.savez_compressed(os.path.join(GOLD, "mssa.npz"), **out)
+    print("wrote mssa.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mssa":
+        gen_mssa()
+        sys.exit(0)
     gen_hvi()
     gen_blocks()
     gen_model()
+    gen_mssa()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

@@ -162,3 +162,35 @@ def test_module_surface(dev):
         y = m(torch.rand(1, 3, 16, 24, device=dev))
     assert y.shape == (1, 3, 16, 24) and torch.isfinite(y).all()
     assert abs(m.trans.this_k - 0.2) < 1e-6
+
+
+def test_spatial_attention_golden(golden, dev):
+    import hvi_cidnet_amd as P
+    g = golden("mssa")
+    m = P.SpatialAttention()
+    m.load_state_dict({"conv1.weight": _t(g["sa_w"])})
+    m.to(dev)
+    x = _t(g["sa_x"], dev).requires_grad_(True)
+    y = m(x)
+    out_ok(y, g["sa_out"], 1e-5, "SA fwd")
+    y.backward(_t(g["sa_gout"], dev))
+    grad_ok(x.grad, g["sa_gx"], what="SA gx")
+    grad_ok(m.conv1.weight.grad, g["sa_gw"], what="SA gw")
+
+
+def test_cidnet_mssa_golden(golden, dev):
+    """config 5 (MSSA): 197 tensors, I_LCA5 live, SpatialAttention after every up block"""
+    import hvi_cidnet_amd as P
+    g = golden("mssa")
+    chans = (12, 12, 24, 48)
+    m = P.CIDNet_MSSA(channels=list(chans))
+    load(m, O.make_params(5, channels=chans, variant="mssa"))
+    m.to(dev)
+    y = m(_t(g["model_x"], dev))
+    d = out_ok(y, g["model_out"], 1e-4, "CIDNet_MSSA fwd")
+    print(f"CIDNet_MSSA fwd max abs diff vs reference: {d:.3e}")
+    (y - _t(g["model_gt"], dev)).abs().mean().backward()
+    for n, prm in m.named_parameters():
+        assert prm.grad is not None, n
+        grad_ok(prm.grad, g[f"model_g.{n}"], rel=2e-4, what=f"d{n}")
+    assert len(m.state_dict()) == 197

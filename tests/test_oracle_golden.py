@@ -92,3 +92,21 @@ def test_lca_blocks_match_reference(golden, kind):
         fn = O.i_lca if kind == "i_lca" else O.hv_lca
         z = fn(_t(g[f"{kind}_{tag}_x"]), _t(g[f"{kind}_{tag}_y"]), p, pre, 2)
         assert torch.equal(z, _t(g[f"{kind}_{tag}_out"]))
+
+
+def test_mssa_matches_reference(golden):
+    """MSSA variant (net/CIDNet_MSSA.py): SpatialAttention block and the whole 197-tensor model."""
+    g = golden("mssa")
+    x, w = _t(g["sa_x"]).requires_grad_(True), _t(g["sa_w"]).requires_grad_(True)
+    y = O.spatial_attention(x, w)
+    assert torch.equal(y.detach(), _t(g["sa_out"]))
+    y.backward(_t(g["sa_gout"]))
+    _close(x.grad, g["sa_gx"])
+    _close(w.grad, g["sa_gw"], rel=1e-5)
+    p = O.params_to(O.make_params(5, channels=(12, 12, 24, 48), variant="mssa"), requires_grad=True)
+    assert len(p) == 197
+    out = O.cidnet_forward(p, _t(g["model_x"]), variant="mssa")
+    assert torch.equal(out.detach(), _t(g["model_out"]))
+    (out - _t(g["model_gt"])).abs().mean().backward()
+    for n, v in p.items():
+        _close(v.grad, g[f"model_g.{n}"], rel=1e-5)
