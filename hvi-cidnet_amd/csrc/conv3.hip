@@ -85,15 +85,28 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   const bool rep = a.replicate != 0;
   const bool single = a.K <= kKC;               // whole weight panel resident: walk `tpb` row tiles
 
+  // consecutive threads walk the contiguous axis of the weight tensor ((k,tap) for the forward
+  // layout, (m,tap) for the data-gradient layout): full-line fetches instead of 4-byte gathers
   auto stage = [&](int kc0, int kcn, int ng) {
-    for (int i = tid; i < ng * 4 * 9 * MB; i += kThreads) {
-      const int mm = i % MB;
-      const int t = (i / MB) % 9;
-      const int kk = i / (MB * 9);
-      float v = 0.f;
-      if (kk < kcn && m0 + mm < a.M)
-        v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
-      As[(kk * 9 + t) * ldA + mm] = v;
+    const int kq = ng * 4;
+    if (a.w_ks == 9) {
+      for (int i = tid; i < MB * kq * 9; i += kThreads) {
+        const int mm = i / (kq * 9), rem = i - mm * (kq * 9);
+        const int kk = rem / 9, t = rem - kk * 9;
+        float v = 0.f;
+        if (kk < kcn && m0 + mm < a.M)
+          v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * 9 + (a.flip ? 8 - t : t)];
+        As[(kk * 9 + t) * ldA + mm] = v;
+      }
+    } else {
+      for (int i = tid; i < kq * MB * 9; i += kThreads) {
+        const int kk = i / (MB * 9), rem = i - kk * (MB * 9);
+        const int mm = rem / 9, t = rem - mm * 9;
+        float v = 0.f;
+        if (kk < kcn && m0 + mm < a.M)
+          v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
+        As[(kk * 9 + t) * ldA + mm] = v;
+      }
     }
   };
   if (single) {

@@ -21,6 +21,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kDepth = 4;     // k-steps of the activation operand prefetched per wave
+long g_pw_target_blocks = 512;   // blocks a launch aims for (each walks several pixel tiles)
 int g_pw_dbg = 0;             // timing-study switches (cidnet_debug_pw_flags): 1 no stores, 2 no K loop, 4 LDS kernel only
 
 struct PwArgs {
@@ -102,12 +103,23 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   const long tile_beg = a.tile0 + (long)blockIdx.x * a.tpb;
   const long tile_end = min(tile_beg + a.tpb, (long)a.ntile_lim);
 
+  // consecutive threads follow the unit-stride axis of the weight tensor (k for the forward layout,
+  // m for the transposed / data-gradient layout), so the panel is fetched in full cache lines
   auto stage = [&](int kc0, int kcn, int kcn4) {
-    for (int i = tid; i < kcn4 * MB; i += kThreads) {
-      const int kk = i / MB, mm = i - kk * MB;
-      float v = 0.f;
-      if (kk < kcn && m0 + mm < a.M) v = Wb[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks];
-      As[kk * ldA + mm] = v;
+    if (a.w_ks == 1) {
+      for (int i = tid; i < kcn4 * MB; i += kThreads) {
+        const int mm = i / kcn4, kk = i - mm * kcn4;
+        float v = 0.f;
+        if (kk < kcn && m0 + mm < a.M) v = Wb[(long)(m0 + mm) * a.w_ms + (kc0 + kk)];
+        As[kk * ldA + mm] = v;
+      }
+    } else {
+      for (int i = tid; i < kcn4 * MB; i += kThreads) {
+        const int kk = i / MB, mm = i - kk * MB;
+        float v = 0.f;
+        if (kk < kcn && m0 + mm < a.M) v = Wb[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks];
+        As[kk * ldA + mm] = v;
+      }
     }
   };
   if (single) {
@@ -231,7 +243,10 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 template <int MT, int EPI, int KS>
 __global__ __launch_bounds__(kThreads) void pw_conv_rega_kernel(PwArgs a) {
   constexpr int MB = 16 * MT;
-  constexpr int D = kDepth;
+  // prefetch distance in k-steps: a whole 9-step tile ahead (~4600 MFMA cycles per wave, and the
+  // co-resident wave doubles it) -- HBM latency under load is several thousand cycles
+  constexpr int D = KS == 24 ? 8 : 9;
+  static_assert(KS % D == 0, "ring slot of step s must be s % D in every tile");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, j = lane >> 4;
   const int b = blockIdx.z;
@@ -272,8 +287,10 @@ __global__ __launch_bounds__(kThreads) void pw_conv_rega_kernel(PwArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const f32x4 xc = ring[ks % D];
-      if (ks + D < KS) ring[ks % D] = load4u(xrow(tile, ks + D));
-      else if (tile + 1 < tile_end) ring[ks % D] = load4u(xrow(tile + 1, ks + D - KS));   // next tile's head
+      if (!(a.dbg & 8)) {
+        if (ks + D < KS) ring[ks % D] = load4u(xrow(tile, ks + D));
+        else if (tile + 1 < tile_end && ks + D - KS < KS) ring[ks % D] = load4u(xrow(tile + 1, ks + D - KS));   // next tile's head
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -326,7 +343,7 @@ template <int MT, int EPI, int KS>
 int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   constexpr int MB = 16 * MT;
   const long mblocks = (a.M + MB - 1) / MB;
-  long tpb = nstream * mblocks * B / 2048;
+  long tpb = (nstream * mblocks * B + g_pw_target_blocks - 1) / g_pw_target_blocks;
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   a.tpb = (int)tpb;
   a.tile0 = 0;
@@ -375,8 +392,8 @@ int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
   if (nstream > 0 && !nstream_done) {
     long tpb = 1;
     if (a.K <= a.kc) {                                       // weights stay resident: walk several tiles
-      tpb = nstream * mblocks * B / 4096;
-      tpb = tpb < 1 ? 1 : (tpb > 4 ? 4 : tpb);
+      tpb = (nstream * mblocks * B + g_pw_target_blocks - 1) / g_pw_target_blocks;
+      tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
     }
     a.tpb = (int)tpb;
     a.tile0 = 0;
@@ -418,8 +435,11 @@ int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
     }
     MT = best;
   } else {
-    const int nblk = (T + 5) / 6;
+    int nblk = (T + 5) / 6;
     MT = (T + nblk - 1) / nblk;
+    // small planes (e.g. 50x75): shrink the channel tile until ~512 blocks exist (never below 2 tiles)
+    const long ntiles = (a.HW + 255) / 256;
+    while (MT > 2 && ntiles * B * ((T + MT - 1) / MT) < 512) --MT;
   }
   switch (MT) {
     case 1: return launch_pw<1>(a, epi, B, s);
@@ -575,7 +595,7 @@ using namespace cidnet;
 
 extern "C" {
 
-void cidnet_debug_pw_flags(int flags) { g_pw_dbg = flags; }
+void cidnet_debug_pw_flags(int flags) { g_pw_dbg = flags & 0xFF; if (flags >> 8) g_pw_target_blocks = flags >> 8; }
 
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
                    const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {

@@ -30,5 +30,7 @@ if __name__ == "__main__":
     shapes = [(8, 190, 36, 60000), (8, 36, 190, 60000), (8, 36, 36, 60000), (8, 36, 95, 60000), (8, 72, 72, 15000),
               (8, 382, 72, 15000), (8, 766, 144, 3750), (8, 144, 766, 3750), (8, 36, 36, 240000)]
     for sh in shapes:
-        r = [run(*sh, flags=f) for f in (0, 1, 2, 3)]
-        print(f"B,M,K,HW={sh}: full {r[0][0]:7.1f} us ({r[0][1]:.2f} TB/s, {r[0][2]:.1f} TF) | no-store {r[1][0]:7.1f} | no-k {r[2][0]:7.1f} | neither {r[3][0]:7.1f}")
+        tb = " ".join(f"{tbk}:{run(*sh, flags=(tbk << 8))[0]:.1f}" for tbk in (256, 512, 768, 1024, 1536, 2048, 4096))
+        print(f"  target-blocks sweep {sh}: {tb}")
+        r = [run(*sh, flags=f | (1024 << 8)) for f in (0, 1, 2, 3, 8, 9, 4)]
+        print(f"B,M,K,HW={sh}: full {r[0][0]:7.1f} us ({r[0][1]:.2f} TB/s, {r[0][2]:.1f} TF) | no-store {r[1][0]:7.1f} | no-k {r[2][0]:7.1f} | neither {r[3][0]:7.1f} | no-load {r[4][0]:7.1f} | no-load-no-store {r[5][0]:7.1f} | LDS-kernel {r[6][0]:7.1f}")
