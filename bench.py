@@ -93,8 +93,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("CIDNET_DP_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import hvi_cidnet_amd as P
@@ -130,11 +133,13 @@ def main():
     lossv = float(loss.item())
     assert lossv == lossv, "loss is NaN"
 
+    # ---- roofline of the dominant kernel family (dense 3x3 conv on the fp32 MFMA), live events ----
+    # every rank runs these extra steps (they contain the gradient all-reduce); only rank 0 instruments
+    timer = OpTimer().install() if rank == 0 else None
+    for _ in range(2):
+        trainer.step(x, gt)
+    sync()
     if rank == 0:
-        # ---- roofline of the dominant kernel family (dense 3x3 conv on the fp32 MFMA), live events --
-        timer = OpTimer().install()
-        for _ in range(2):
-            trainer.step(x, gt)
         agg = timer.table()
         timer.remove()
         tot = sum(v[1] for v in agg.values())
@@ -168,16 +173,32 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
 
 
 def cpu_baseline(a):
     """The oracle (port of the reference algorithm, plain PyTorch CPU eager) forward+backward on a
     bounded sample: 2 images of the same 3xHxW shape (1/4 of one GPU batch), all host cores."""
     from oracle import cidnet_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     p = O.params_to(O.make_params(0, jitter=False), requires_grad=True)
     n = 2

@@ -26,6 +26,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -73,6 +75,8 @@ class DataParallelTrainer:
         self.loss_fn = loss_fn or _default_loss
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # rehearsal switch: run the bucket all-reduces even on a 1-rank group (exercises the RCCL path on one GPU)
+        self._force_comm = dist.is_initialized() and os.environ.get("CIDNET_DP_FORCE_ALLREDUCE") == "1"
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.n_buckets = max(1, n_buckets)
         self.use_hip = use_hip_kernels
@@ -126,7 +130,7 @@ class DataParallelTrainer:
             off += n
         self.flat_p, self.n_live = flat_p, n_live
         # identical initial weights on every rank
-        if self.world > 1:
+        if self.world > 1 or self._force_comm:
             dist.broadcast(self.flat_p, src=0, group=self.pg)
         # 3) buckets: contiguous, roughly equal, cut at parameter boundaries
         target = (n_live + self.n_buckets - 1) // self.n_buckets
@@ -163,7 +167,7 @@ class DataParallelTrainer:
         p.grad = None                               # the arena is the single home of gradients
         bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.world > 1:
+        if self._pending[bi] == 0 and (self.world > 1 or self._force_comm):
             start, cnt, _ = self.buckets[bi]
             self._handles.append(dist.all_reduce(self.flat_g[start:start + cnt], op=dist.ReduceOp.SUM, group=self.pg,
                                                  async_op=True))

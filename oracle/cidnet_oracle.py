@@ -20,6 +20,7 @@ in float32 or float64 (`params_to(params, torch.float64)`).
 from __future__ import annotations
 
 import math
+import re
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -218,6 +219,114 @@ def i_lca(x, y, p: Params, pre: str, heads: int):
     return x + iel(layernorm_cf(x, nw, nb), p, pre + ".gdfn")
 
 
+# --------------------------------------------------------------------------------------
+# TNSM variant blocks (net/TNSM.py)
+# --------------------------------------------------------------------------------------
+def dynamic_noise_map(x, p: Params, pre: str):
+    """`DynamicNoiseMap.forward`, net/TNSM.py:37-57 -> (B,1,H,W) noise map in (0,1)."""
+    c = x.shape[1]
+    avg = F.adaptive_avg_pool2d(x, 1)
+    mx = F.adaptive_max_pool2d(x, 1)
+    fc = lambda t: F.conv2d(F.relu(F.conv2d(t, p[pre + ".fc1.weight"])), p[pre + ".fc2.weight"])
+    global_feat = torch.sigmoid(fc(avg) + fc(mx))
+    local = F.conv2d(F.leaky_relu(F.conv2d(x, p[pre + ".noise_branch.0.weight"], padding=1, groups=c), 0.2),
+                     p[pre + ".noise_branch.2.weight"])
+    return torch.sigmoid(F.conv2d(global_feat * local, p[pre + ".final_conv.weight"]))
+
+
+def noise_aware_attention(x, y, noise_map, p: Params, pre: str, heads: int):
+    """`NoiseAwareAttentionCABStyle.forward`, net/TNSM.py:83-128: CAB without the L2 normalisation of
+    q,k, with v modulated by sigmoid(conv1x1(noise_map))."""
+    b, c, h, w = x.shape
+    q = F.conv2d(F.conv2d(x, p[pre + ".q.weight"]), p[pre + ".q_dwconv.weight"], padding=1, groups=c)
+    kv = F.conv2d(F.conv2d(y, p[pre + ".kv.weight"]), p[pre + ".kv_dwconv.weight"], padding=1, groups=2 * c)
+    k, v = kv.chunk(2, dim=1)
+    q = q.reshape(b, heads, c // heads, h * w)
+    k = k.reshape(b, heads, c // heads, h * w)
+    v = v.reshape(b, heads, c // heads, h * w)
+    attn = ((q @ k.transpose(-2, -1)) * p[pre + ".temperature"]).softmax(dim=-1)
+    keep = torch.sigmoid(F.conv2d(noise_map, p[pre + ".noise_scaler.0.weight"]))
+    v = v * keep.reshape(b, heads, c // heads, h * w)
+    out = (attn @ v).reshape(b, c, h, w)
+    return F.conv2d(out, p[pre + ".project_out.weight"])
+
+
+def adaptive_filter(x, noise_map, p: Params, pre: str):
+    """`AdaptiveFilter.forward`, net/TNSM.py:155-173."""
+    c = x.shape[1]
+    nb = F.conv2d(F.leaky_relu(F.conv2d(x, p[pre + ".noise_process.0.weight"], padding=1, groups=c), 0.2),
+                  p[pre + ".noise_process.2.weight"])
+    db = F.conv2d(F.leaky_relu(F.conv2d(x, p[pre + ".detail_preserve.0.weight"]), 0.2),
+                  p[pre + ".detail_preserve.2.weight"], padding=1, groups=c)
+    fused = torch.cat([noise_map * nb, (1.0 - noise_map) * db], dim=1)
+    out = F.conv2d(fused, p[pre + ".fusion.weight"])
+    return layernorm_cf(out, p[pre + ".norm.weight"], p[pre + ".norm.bias"])
+
+
+def tnsm_block(x, y, p: Params, pre: str, heads: int):
+    """`TrainableNoiseSuppression.forward`, net/TNSM.py:196-215 (HV_TNSM / I_TNSM wrap it as `.tnsm`)."""
+    pre = pre + ".tnsm"
+    nm = dynamic_noise_map(x, p, pre + ".noise_map_generator")
+    n1w, n1b = p[pre + ".norm1.weight"], p[pre + ".norm1.bias"]
+    x = x + noise_aware_attention(layernorm_cf(x, n1w, n1b), layernorm_cf(y, n1w, n1b), nm, p, pre + ".noise_attention", heads)
+    x = x + adaptive_filter(layernorm_cf(x, p[pre + ".norm2.weight"], p[pre + ".norm2.bias"]), nm, p, pre + ".adaptive_filter")
+    return x, nm
+
+
+def cidnet_tnsm_forward(p: Params, x: torch.Tensor, heads=(1, 2, 4, 8), training: bool = True, this_k: Optional[float] = None):
+    """`CIDNet_TNSM.forward` (use_tnsm=True), net/CIDNet_TNSM.py:101-294 -> (rgb, fused_noise or None).
+    Same wiring quirks as the base model (level-3 encoders see the pre-LCA2 tensors; ID_block2 is fed
+    i_dec3, so I_LCA5 and I_TNSM5 are dead); twelve noise maps are resized (bilinear,
+    align_corners=False) and fused by conv3x3(12->3)+sigmoid in training mode only (:248-266)."""
+    _, h2, h3, h4 = heads
+    k = p["trans.density_k"]
+    hvi = hvit(x, k)
+    if this_k is None:
+        this_k = float(k.detach().reshape(-1)[0])
+    maps = []
+    i_enc0 = rep_conv3x3(hvi[:, 2:3], p["IE_block0.1.weight"])
+    i_enc1 = norm_downsample(i_enc0, p, "IE_block1")
+    hv_0 = rep_conv3x3(hvi, p["HVE_block0.1.weight"])
+    hv_1 = norm_downsample(hv_0, p, "HVE_block1")
+    i_jump0, hv_jump0 = i_enc0, hv_0
+
+    def stage(i_in, hv_in, n, hd):
+        """I_LCAn / HV_LCAn followed by I_TNSMn / HV_TNSMn (both TNSMs see the LCA outputs)"""
+        i_l = i_lca(i_in, hv_in, p, f"I_LCA{n}", hd)
+        hv_l = hv_lca(hv_in, i_in, p, f"HV_LCA{n}", hd)
+        i_t, i_n = tnsm_block(i_l, hv_l, p, f"I_TNSM{n}", hd)
+        hv_t, hv_n = tnsm_block(hv_l, i_l, p, f"HV_TNSM{n}", hd)
+        maps.extend([i_n, hv_n])
+        return i_t, hv_t
+
+    i_enc2, hv_2 = stage(i_enc1, hv_1, 1, h2)
+    v_jump1, hv_jump1 = i_enc2, hv_2
+    i_enc2 = norm_downsample(i_enc2, p, "IE_block2")
+    hv_2 = norm_downsample(hv_2, p, "HVE_block2")
+    v_jump2, hv_jump2 = stage(i_enc2, hv_2, 2, h3)
+    i_enc3 = norm_downsample(i_enc2, p, "IE_block3")
+    hv_3 = norm_downsample(hv_2, p, "HVE_block3")
+    i_enc4, hv_4 = stage(i_enc3, hv_3, 3, h4)
+    i_dec4, hv_4 = stage(i_enc4, hv_4, 4, h4)
+    hv_3 = norm_upsample(hv_4, hv_jump2, p, "HVD_block3")
+    i_dec3 = norm_upsample(i_dec4, v_jump2, p, "ID_block3")
+    i_dec2_dead, hv_2 = stage(i_dec3, hv_3, 5, h3)        # the I branch result is discarded (:213 vs :226)
+    hv_2 = norm_upsample(hv_2, hv_jump1, p, "HVD_block2")
+    i_dec2 = norm_upsample(i_dec3, v_jump1, p, "ID_block2")
+    i_dec1, hv_1 = stage(i_dec2, hv_2, 6, h2)
+    i_dec1 = norm_upsample(i_dec1, i_jump0, p, "ID_block1")
+    i_dec0 = rep_conv3x3(i_dec1, p["ID_block0.1.weight"])
+    hv_1 = norm_upsample(hv_1, hv_jump0, p, "HVD_block1")
+    hv_0 = rep_conv3x3(hv_1, p["HVD_block0.1.weight"])
+    rgb = phvit(torch.cat([hv_0, i_dec0], dim=1) + hvi, this_k)
+    if not training:
+        return rgb, None
+    H, W = rgb.shape[-2:]
+    resized = [m if m.shape[-2:] == (H, W) else F.interpolate(m, size=(H, W), mode="bilinear", align_corners=False) for m in maps]
+    fused = torch.sigmoid(F.conv2d(torch.cat(resized, dim=1), p["noise_fusion.0.weight"], padding=1))
+    return rgb, fused
+
+
 def spatial_attention(x, w):
     """`SpatialAttention.forward` of the MSSA variant, net/CIDNet_MSSA.py:20-25:
     x * sigmoid(conv7x7([mean_c(x), max_c(x)])), zero pad 3, no bias."""
@@ -356,7 +465,42 @@ def param_shapes(channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), variant: str = 
         hv_lca_(f"HV_LCA{n}", d, nh)
     for n, (d, nh) in enumerate([(c2, h2), (c3, h3), (c4, h4), (c4, h4), (c3, h3), (c2, h2)], 1):
         i_lca_(f"I_LCA{n}", d, nh)
+    if variant == "tnsm":
+        def tnsm_(pre, d, nh):
+            r = max(8, d // 4)
+            g = pre + ".tnsm.noise_map_generator"
+            s[g + ".fc1.weight"] = (r, d, 1, 1)
+            s[g + ".fc2.weight"] = (d, r, 1, 1)
+            s[g + ".noise_branch.0.weight"] = (d, 1, 3, 3)
+            s[g + ".noise_branch.2.weight"] = (d, d, 1, 1)
+            s[g + ".final_conv.weight"] = (1, d, 1, 1)
+            a = pre + ".tnsm.noise_attention"
+            s[a + ".temperature"] = (nh, 1, 1)
+            s[a + ".q.weight"] = (d, d, 1, 1)
+            s[a + ".q_dwconv.weight"] = (d, 1, 3, 3)
+            s[a + ".kv.weight"] = (2 * d, d, 1, 1)
+            s[a + ".kv_dwconv.weight"] = (2 * d, 1, 3, 3)
+            s[a + ".noise_scaler.0.weight"] = (d, 1, 1, 1)
+            s[a + ".project_out.weight"] = (d, d, 1, 1)
+            f = pre + ".tnsm.adaptive_filter"
+            s[f + ".noise_process.0.weight"] = (d, 1, 3, 3)
+            s[f + ".noise_process.2.weight"] = (d, d, 1, 1)
+            s[f + ".detail_preserve.0.weight"] = (d, d, 1, 1)
+            s[f + ".detail_preserve.2.weight"] = (d, 1, 3, 3)
+            s[f + ".fusion.weight"] = (d, 2 * d, 1, 1)
+            s[f + ".norm.weight"] = (d,)
+            s[f + ".norm.bias"] = (d,)
+            for nn_ in ("norm1", "norm2"):
+                s[pre + f".tnsm.{nn_}.weight"] = (d,)
+                s[pre + f".tnsm.{nn_}.bias"] = (d,)
+        lv = [(c2, h2), (c3, h3), (c4, h4), (c4, h4), (c3, h3), (c2, h2)]
+        for n, (d, nh) in enumerate(lv, 1):
+            tnsm_(f"HV_TNSM{n}", d, nh)
+        for n, (d, nh) in enumerate(lv, 1):
+            tnsm_(f"I_TNSM{n}", d, nh)
     s["trans.density_k"] = (1,)
+    if variant == "tnsm":
+        s["noise_fusion.0.weight"] = (3, 12, 3, 3)
     if variant == "mssa":
         for n in ("sa_hv3", "sa_i3", "sa_hv2", "sa_i2", "sa_hv1", "sa_i1"):
             s[n + ".conv1.weight"] = (1, 2, 7, 7)
@@ -382,9 +526,9 @@ def make_params(seed: int = 0, channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), j
     for key, shape in param_shapes(channels, heads, variant).items():
         rng = np.random.Generator(np.random.PCG64(_key_seed(seed, key)))
         u = rng.random(shape, dtype=np.float64) * 2.0 - 1.0
-        if key.endswith("norm.weight"):
+        if re.search(r"norm\d*\.weight$", key):
             v = 1.0 + (0.2 * u if jitter else 0.0 * u)
-        elif key.endswith("norm.bias"):
+        elif re.search(r"norm\d*\.bias$", key):
             v = 0.1 * u if jitter else 0.0 * u
         elif key.endswith("prelu.weight"):
             v = 0.25 + (0.1 * u if jitter else 0.0 * u)

@@ -357,13 +357,84 @@ def gen_mssa():
     print("wrote mssa.npz", len(out), "arrays")
 
 
+def gen_tnsm():
+    """TNSM variant (net/TNSM.py, net/CIDNet_TNSM.py): one TNSM block + whole model in training mode
+    (returns (rgb, fused_noise)), reduced width, all gradients."""
+    from net.CIDNet_TNSM import CIDNet_TNSM as RefTNSM
+    from net.TNSM import HV_TNSM as RefHVTNSM
+    out = {}
+    chans = (12, 12, 24, 48)
+    p = O.make_params(9, channels=chans, variant="tnsm")
+    blk = RefHVTNSM(chans[1], 2)
+    load_into(blk, p, "HV_TNSM1.")
+    x = O.synthetic_batch(81, (2, chans[1], 20, 28)) - 0.5
+    y = O.synthetic_batch(82, (2, chans[1], 20, 28)) - 0.5
+    xr, yr_ = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    zr, nr = blk(xr, yr_)
+    gz = O.synthetic_batch(83, tuple(zr.shape)) - 0.5
+    gn = O.synthetic_batch(84, tuple(nr.shape)) - 0.5
+    (zr * gz).sum().add((nr * gn).sum()).backward()
+    po = O.params_to(p, requires_grad=True)
+    xo, yo_ = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    zo, no = O.tnsm_block(xo, yo_, po, "HV_TNSM1", 2)
+    (zo * gz).sum().add((no * gn).sum()).backward()
+    check_equal(zo, zr, "TNSM block fwd")
+    check_equal(no, nr, "TNSM block noise map")
+    check_equal(xo.grad, xr.grad, "TNSM block dx", exact=False, tol=1e-5)
+    check_equal(yo_.grad, yr_.grad, "TNSM block dy", exact=False, tol=1e-5)
+    out.update(blk_x=x.numpy(), blk_y=y.numpy(), blk_out=zr.detach().numpy(), blk_noise=nr.detach().numpy(),
+               blk_gout=gz.numpy(), blk_gnoise=gn.numpy(), blk_gx=xr.grad.numpy(), blk_gy=yr_.grad.numpy())
+    for n, prm in blk.named_parameters():
+        check_equal(po["HV_TNSM1." + n].grad, prm.grad, f"TNSM block d{n}", exact=False, tol=5e-5)
+        out[f"blk_g.{n}"] = prm.grad.numpy()
+    p = O.make_params(5, channels=chans, variant="tnsm")
+    m = RefTNSM(channels=list(chans))
+    load_into(m, p)
+    assert len(m.state_dict()) == 468
+    m.train()
+    x = O.synthetic_batch(51, (2, 3, 32, 48))
+    gt = O.synthetic_batch(52, (2, 3, 32, 48))
+    yr, fr = m(x)
+    ((yr - gt).abs().mean() + 0.1 * fr.mean()).backward()
+    po = O.params_to(p, requires_grad=True)
+    yo, fo = O.cidnet_tnsm_forward(po, x)
+    ((yo - gt).abs().mean() + 0.1 * fo.mean()).backward()
+    check_equal(yo, yr, "CIDNet_TNSM fwd rgb")
+    check_equal(fo, fr, "CIDNet_TNSM fwd fused noise")
+    m.eval()
+    with torch.no_grad():
+        ye, fe = m(x)
+    assert fe is None
+    check_equal(O.cidnet_tnsm_forward(p, x, training=False)[0], ye, "CIDNet_TNSM eval fwd")
+    out.update(model_x=x.numpy(), model_gt=gt.numpy(), model_out=yr.detach().numpy(), model_noise=fr.detach().numpy())
+    worst, dead = 0.0, []
+    for n, prm in m.named_parameters():
+        if prm.grad is None:
+            dead.append(n)
+            assert po[n].grad is None, n
+            continue
+        d = (prm.grad - po[n].grad).abs().max().item() / max(prm.grad.abs().max().item(), 1e-30)
+        worst = max(worst, d)
+        out[f"model_g.{n}"] = prm.grad.numpy()
+    assert all(n.startswith(("I_LCA5.", "I_TNSM5.")) for n in dead), dead
+    out["model_dead"] = np.array(dead)
+    print(f"  ok  CIDNet_TNSM grads: worst rel-to-max diff {worst:.2e}; {len(dead)} dead tensors (I_LCA5.*, I_TNSM5.*)")
+    assert worst < 1e-4
+    np.savez_compressed(os.path.join(GOLD, "tnsm.npz"), **out)
+    print("wrote tnsm.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mssa":
         gen_mssa()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tnsm":
+        gen_tnsm()
         sys.exit(0)
     gen_hvi()
     gen_blocks()
     gen_model()
     gen_mssa()
+    gen_tnsm()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
