@@ -9,8 +9,10 @@ ROCm device and libcidnet_hip.so must be built (`python hvi-cidnet_amd/build.py`
 from . import _lib  # noqa: F401
 from .cidnet import CIDNet
 from .cidnet_mssa import CIDNet as CIDNet_MSSA, SpatialAttention
+from .cidnet_tnsm import CIDNet_TNSM
+from .tnsm import HV_TNSM, I_TNSM, TrainableNoiseSuppression
 from .hvi_transform import RGB_HVI
 from .lca import CAB, IEL, HV_LCA, I_LCA
 from .transformer_utils import LayerNorm, NormDownsample, NormUpsample
 
-__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample"]
+__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample"]

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void softmax_fwd_kernel(const float* __re
                                                                const float* __restrict__ Wp, float* __restrict__ attn,
                                                                float* __restrict__ shat, float* __restrict__ nqo,
                                                                float* __restrict__ nko, float* __restrict__ Mout, int C,
-                                                               int heads) {
+                                                               int heads, int normalize) {
   extern __shared__ float sm[];          // [ch*ch + 2ch] sums, then attn [ch*ch]
   const int ch = C / heads;
   const int head = blockIdx.x, b = blockIdx.y;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void softmax_fwd_kernel(const float* __re
   __syncthreads();
   const float T = temperature[head];
   for (int i = threadIdx.x; i < 2 * ch; i += blockDim.x) {
-    const float nv = fmaxf(sqrtf(S[ch * ch + i]), kNormEps);
+    const float nv = normalize ? fmaxf(sqrtf(S[ch * ch + i]), kNormEps) : 1.0f;   // TNSM attention: raw dot products
     S[ch * ch + i] = nv;
     if (i < ch) nqo[(long)b * C + head * ch + i] = nv; else nko[(long)b * C + head * ch + (i - ch)] = nv;
   }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
                                                                const float* __restrict__ nq, const float* __restrict__ nk,
                                                                const float* __restrict__ temperature, float* __restrict__ dWp_b,
                                                                float* __restrict__ dT_b, float* __restrict__ Wqk, int C,
-                                                               int heads) {
+                                                               int heads, int normalize) {
   extern __shared__ float sm[];    // A[ch*ch], G[ch*ch] (dattn -> dShat), red[ch], red2[ch]
   __shared__ float red[kThreads / 64];
   const int ch = C / heads;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
     if (lr < ch) {
       const int row = lr;
       if (col == head * ch + row) {
-        v = (nqb[row] > kNormEps) ? -ai[row] / (nqb[row] * nqb[row]) : 0.f;
+        v = (normalize && nqb[row] > kNormEps) ? -ai[row] / (nqb[row] * nqb[row]) : 0.f;
       } else if (col >= C + head * ch && col < C + head * ch + ch) {
         const int c = col - C - head * ch;
         v = G[row * ch + c] / (nqb[row] * nkb[c]);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
     } else {
       const int c = lr - ch;
       if (col == C + head * ch + c) {
-        v = (nkb[c] > kNormEps) ? -ej[c] / (nkb[c] * nkb[c]) : 0.f;
+        v = (normalize && nkb[c] > kNormEps) ? -ej[c] / (nkb[c] * nkb[c]) : 0.f;
       } else if (col >= head * ch && col < head * ch + ch) {
         const int row = col - head * ch;
         v = G[row * ch + c] / (nqb[row] * nkb[c]);
@@ -257,7 +257,7 @@ long cidnet_attn_gram_ws_floats(int B, int C, int heads, long HW) {
 
 /* fwd: gram + softmax + fold with project_out.  Outputs attn/shat (B,heads,ch,ch), nq/nk (B,C), M (B,C,C). */
 int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp, float* attn, float* shat, float* nq,
-                    float* nk, float* M, float* ws, long ws_floats, int B, int C, int heads, long HW, void* stream) {
+                    float* nk, float* M, float* ws, long ws_floats, int B, int C, int heads, long HW, int normalize, void* stream) {
   CIDNET_CHECK_ARG(qkv && temperature && Wp && attn && shat && nq && nk && M && ws && B > 0 && C > 0 && heads > 0 && HW > 0);
   if (C % heads != 0 || C / heads > 32) return CIDNET_ERR_SHAPE;
   if (ws_floats < cidnet_attn_gram_ws_floats(B, C, heads, HW)) return CIDNET_ERR_WS;
@@ -271,19 +271,20 @@ int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp,
   CIDNET_LAUNCH_STATUS();
   const size_t lds = (size_t)(2 * ch * ch + 2 * ch) * sizeof(float);
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)heads, (unsigned)B), dim3(kThreads), lds, s, ws, chunks * 4,
-                     temperature, Wp, attn, shat, nq, nk, M, C, heads);
+                     temperature, Wp, attn, shat, nq, nk, M, C, heads, normalize);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
 int cidnet_attn_bwd(const float* dM, const float* Wp, const float* attn, const float* shat, const float* nq, const float* nk,
-                    const float* temperature, float* dWp_b, float* dT_b, float* Wqk, int B, int C, int heads, void* stream) {
+                    const float* temperature, float* dWp_b, float* dT_b, float* Wqk, int B, int C, int heads, int normalize,
+                    void* stream) {
   CIDNET_CHECK_ARG(dM && Wp && attn && shat && nq && nk && temperature && dWp_b && dT_b && Wqk && B > 0 && C > 0 && heads > 0);
   if (C % heads != 0 || C / heads > 32) return CIDNET_ERR_SHAPE;
   const int ch = C / heads;
   const size_t lds = (size_t)(2 * ch * ch + 2 * ch) * sizeof(float);
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)heads, (unsigned)B), dim3(kThreads), lds, (hipStream_t)stream, dM, Wp,
-                     attn, shat, nq, nk, temperature, dWp_b, dT_b, Wqk, C, heads);
+                     attn, shat, nq, nk, temperature, dWp_b, dT_b, Wqk, C, heads, normalize);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

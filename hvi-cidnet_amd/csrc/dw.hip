@@ -13,6 +13,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kRows = 8;
+constexpr int kSub = 4;     // 256-item groups a fused-backward block walks before reducing
 
 struct Row6 {
   float v[6];
@@ -213,6 +214,67 @@ __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __re
   }
 }
 
+// Fused depthwise backward: one pass over (gout, in) produces BOTH the data gradient
+//   gin[y][x] = sum_tap w[8-tap] * gout[y+dy-1][x+dx-1]  (+ addend)
+// and the per-block partial of the weight gradient gw[tap] = sum gout[y][x] * in[y+dy-1][x+dx-1]:
+// gout is read once instead of twice (3 tensor passes instead of 4).
+__global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                             const float* __restrict__ w1, const float* __restrict__ w2, int csplit,
+                                                             const float* __restrict__ addend, float* __restrict__ gin,
+                                                             float* __restrict__ part, int C, int H, int W, int nchunk) {
+  __shared__ float red[kThreads / 64];
+  const int nxg = (((W + 3) >> 2) + 15) >> 4;
+  const int nstrips = (H + kRows - 1) / kRows;
+  const long bc = blockIdx.y;
+  const long HW = (long)H * W;
+  const float* ip = in + bc * HW;
+  const float* gp = gout + bc * HW;
+  const float* ap = addend ? addend + bc * HW : nullptr;
+  float* op = gin + bc * HW;
+  float w[9];
+  load_w9(w1, w2, csplit, (int)(bc % C), true, w);
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  // a block walks kSub consecutive 256-item groups of the plane so the nine block reductions below
+  // are paid once per 4 * 8192 pixels
+  for (int sub = 0; sub < kSub; ++sub) {
+    const long idx = ((long)blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
+    const int xl = (int)(idx & 15);
+    const long rest = idx >> 4;
+    const int xg = (int)(rest % nxg), strip = (int)(rest / nxg);
+    const int x0 = (xg * 16 + xl) * 4, y0 = strip * kRows;
+    if (!(strip < nstrips && x0 < W)) continue;
+    Row6 i0 = load_row6(ip, y0 - 1, x0, H, W), i1 = load_row6(ip, y0, x0, H, W);
+    Row6 g0 = load_row6(gp, y0 - 1, x0, H, W), g1 = load_row6(gp, y0, x0, H, W);
+    const int yend = min(y0 + kRows, H);
+    for (int y = y0; y < yend; ++y) {
+      const Row6 i2 = load_row6(ip, y + 1, x0, H, W);
+      const Row6 g2 = load_row6(gp, y + 1, x0, H, W);
+      f32x4 o = stencil(g0, g1, g2, w);
+      if (ap) {
+        const Row6 a = load_row6(ap, y, x0, H, W);
+        o[0] += a.v[1]; o[1] += a.v[2]; o[2] += a.v[3]; o[3] += a.v[4];
+      }
+      store_row4(op, y, x0, W, o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gv = g1.v[1 + e];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          acc[dx] += gv * i0.v[e + dx]; acc[3 + dx] += gv * i1.v[e + dx]; acc[6 + dx] += gv * i2.v[e + dx];
+        }
+      }
+      i0 = i1; i1 = i2; g0 = g1; g1 = g2;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float sres = block_sum(acc[t], red);
+    if (threadIdx.x == 0) part[(bc * nchunk + blockIdx.x) * 9 + t] = sres;
+  }
+}
+
 // gw[c][t] (+)= sum_b sum_chunk part[((b*C + c)*nchunk + chunk)*9 + t]
 __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int B, int C, int nchunk, float* __restrict__ gw1,
                                        float* __restrict__ gw2, int csplit) {
@@ -282,6 +344,23 @@ int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B,
                      C, nchunk, gw1, gw2, csplit);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+/* data gradient and weight gradient of a depthwise 3x3 in one pass: gin = dw3x3(gout, flipped taps)
+ * [+ addend]; gw = sum gout * shifted(in).  ws as cidnet_dw3x3_wgrad. */
+int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const float* w2, int csplit, const float* addend,
+                     float* gin, float* gw1, float* gw2, float* ws, long ws_floats, int B, int C, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(in && gout && w1 && gin && gw1 && ws && B > 0 && C > 0 && H > 0 && W > 0);
+  CIDNET_CHECK_ARG(csplit >= C || (w2 && gw2));
+  if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
+  const int nchunk = (wgrad_chunks(H, W) + kSub - 1) / kSub;
+  hipLaunchKernelGGL(dw3x3_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(kThreads), 0, (hipStream_t)stream, in, gout,
+                     w1, w2, csplit, addend, gin, ws, C, H, W, nchunk);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, C,
+                     nchunk, gw1, gw2, csplit);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -21,6 +21,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kDepth = 4;     // k-steps of the activation operand prefetched per wave
+int g_pw_force_mt = 0;          // timing studies: force the channel-tile count per block
 long g_pw_target_blocks = 512;   // blocks a launch aims for (each walks several pixel tiles)
 int g_pw_dbg = 0;             // timing-study switches (cidnet_debug_pw_flags): 1 no stores, 2 no K loop, 4 LDS kernel only
 
@@ -434,6 +435,7 @@ int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
       if (pad < best_pad) { best_pad = pad; best = mt; }
     }
     MT = best;
+    if (g_pw_force_mt >= 1 && g_pw_force_mt <= mtmax) MT = g_pw_force_mt;
   } else {
     int nblk = (T + 5) / 6;
     MT = (T + nblk - 1) / nblk;
@@ -595,7 +597,11 @@ using namespace cidnet;
 
 extern "C" {
 
-void cidnet_debug_pw_flags(int flags) { g_pw_dbg = flags & 0xFF; if (flags >> 8) g_pw_target_blocks = flags >> 8; }
+void cidnet_debug_pw_flags(int flags) {
+  g_pw_dbg = flags & 0xFF;
+  g_pw_force_mt = (flags >> 28) & 7;
+  if ((flags >> 8) & 0xFFFFF) g_pw_target_blocks = (flags >> 8) & 0xFFFFF;
+}
 
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
                    const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {

@@ -181,6 +181,14 @@ def dw3x3_wgrad(inp, gout, gw1, gw2, csplit, B, C, H, W):
     lib().call("cidnet_dw3x3_wgrad", _p(inp), _p(gout), _p(gw1), _p(gw2), csplit, _p(ws), ws.numel(), B, C, H, W, _stream())
 
 
+def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None):
+    """data gradient (+ addend) and weight gradient of a depthwise 3x3 in one pass"""
+    n = _raw("cidnet_dw3x3_wgrad_ws_floats", B, C, H, W)
+    ws = _ws(n, inp.device)
+    lib().call("cidnet_dw3x3_bwd", _p(inp), _p(gout), _p(w1), _p(w2), csplit, _p(addend), _p(gin), _p(gw1), _p(gw2), _p(ws),
+               ws.numel(), B, C, H, W, _stream())
+
+
 def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False):
     lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
                H, W, _stream())
@@ -268,7 +276,7 @@ class CABResidualFn(torch.autograd.Function):
         n = _raw("cidnet_attn_gram_ws_floats", B, C, heads, HW)
         ws = _ws(n, dev)
         lib().call("cidnet_attn_fwd", _p(qkv), _p(temperature), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(M), _p(ws),
-                   ws.numel(), B, C, heads, HW, _stream())
+                   ws.numel(), B, C, heads, HW, 1, _stream())
         out = torch.empty_like(x_res)
         pw_conv(qkv, 2 * C * HW, 3 * C * HW, M, 0, C * C, C, 1, out, 0, C * HW, B, C, C, HW, res=x_res, r_bs=C * HW)
         ctx.save_for_backward(xn, yn, qkv0, qkv, attn, shat, nq, nk, M, temperature, wq, wq_dw, wkv, wkv_dw, wp)
@@ -292,7 +300,7 @@ class CABResidualFn(torch.autograd.Function):
         dT_b = torch.empty((B, heads), device=dev, dtype=torch.float32)
         wqk = torch.empty((B, 2 * C, 2 * C), device=dev, dtype=torch.float32)
         lib().call("cidnet_attn_bwd", _p(dM), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(temperature), _p(dwp_b), _p(dT_b),
-                   _p(wqk), B, C, heads, _stream())
+                   _p(wqk), B, C, heads, 1, _stream())
         g_wp = grad_like(wp)
         lib().call("cidnet_sum_rows", _p(dwp_b), B, C * C, _p(g_wp), _stream())
         g_T = grad_like(temperature)
@@ -302,9 +310,8 @@ class CABResidualFn(torch.autograd.Function):
         # depthwise backward
         g_wq_dw = grad_like(wq_dw)
         g_wkv_dw = grad_like(wkv_dw)
-        dw3x3_wgrad(qkv0, dqkv, g_wq_dw, g_wkv_dw, C, B, 3 * C, H, W)
         dqkv0 = torch.empty_like(qkv0)
-        dw3x3(dqkv, wq_dw, wkv_dw, C, dqkv0, B, 3 * C, H, W, flip=True)
+        dw3x3_bwd(qkv0, dqkv, wq_dw, wkv_dw, C, dqkv0, g_wq_dw, g_wkv_dw, B, 3 * C, H, W)
         # pointwise backward
         g_wq = grad_like(wq)
         g_wkv = grad_like(wkv)
@@ -363,13 +370,11 @@ class IELFn(torch.autograd.Function):
         lib().call("cidnet_iel_gate_bwd", _p(u), _p(w_dw1), _p(w_dw2), _p(dg), _p(da), _p(ds), B, h, H, W, _stream())
         g_dw1 = grad_like(w_dw1)
         g_dw2 = grad_like(w_dw2)
-        dw3x3_wgrad(u, da, g_dw1, g_dw2, h, B, 2 * h, H, W)
         du = ds                                         # du = ds + dw^T(da), written in place over ds
-        dw3x3(da, w_dw1, w_dw2, h, du, B, 2 * h, H, W, flip=True, addend=ds)
+        dw3x3_bwd(u, da, w_dw1, w_dw2, h, du, g_dw1, g_dw2, B, 2 * h, H, W, addend=ds)
         g_dw = grad_like(w_dw)
-        dw3x3_wgrad(pin, du, g_dw, None, 2 * h, B, 2 * h, H, W)
         dpin = da                                       # reuse
-        dw3x3(du, w_dw, None, 2 * h, dpin, B, 2 * h, H, W, flip=True)
+        dw3x3_bwd(pin, du, w_dw, None, 2 * h, dpin, g_dw, None, B, 2 * h, H, W)
         g_win = grad_like(w_in)
         pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW)
         dxn = None
@@ -616,3 +621,328 @@ def grad_like(w):
         if 0 <= off < n and w.data_ptr() not in excl and w.is_contiguous():
             return flat_g[off:off + w.numel()].view(w.shape)
     return torch.empty_like(w)
+
+
+# --------------------------------------------------------------------------------------------
+# generic conv pieces used by the TNSM variant (net/TNSM.py)
+# --------------------------------------------------------------------------------------------
+class PwConvFn(torch.autograd.Function):
+    """Y = W[:, col_off:col_off+K] * X (1x1 conv on a column slice of a wider weight, bias-free)."""
+
+    @staticmethod
+    def forward(ctx, x, w, col_off, K):
+        _check(x, w)
+        x = _c(x)
+        B, Kx, H, W = x.shape
+        M, Kw = w.shape[0], w.shape[1]
+        if Kx != K:
+            raise RuntimeError("PwConvFn: channel mismatch")
+        y = torch.empty((B, M, H, W), device=x.device, dtype=torch.float32)
+        pw_conv(x, 0, K * H * W, w, col_off, 0, Kw, 1, y, 0, M * H * W, B, M, K, H * W)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (col_off, K)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        col_off, K = ctx.meta
+        B, _, H, W = x.shape
+        M, Kw = w.shape[0], w.shape[1]
+        HW = H * W
+        g = _c(g)
+        full = (col_off == 0 and K == Kw)
+        gw = grad_like(w) if full else torch.zeros_like(w)
+        pw_wgrad(g, 0, M * HW, x, 0, K * HW, gw, col_off, Kw, B, M, K, HW)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            pw_conv(g, 0, M * HW, w, col_off, 0, 1, Kw, gx, 0, K * HW, B, K, M, HW)
+        return gx, gw, None, None
+
+
+class DwConvFn(torch.autograd.Function):
+    """depthwise 3x3 (zero pad), optionally followed by LeakyReLU(0.2)"""
+
+    @staticmethod
+    def forward(ctx, x, w, leaky):
+        _check(x, w)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        dw3x3(x, w, None, C, y, B, C, H, W)
+        if leaky:
+            lib().call("cidnet_elementwise", 0, _p(y), None, _p(y), y.numel(), _stream())
+        ctx.save_for_backward(x, w, y if leaky else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = _c(g)
+        if y is not None:
+            gp = torch.empty_like(g)
+            lib().call("cidnet_elementwise", 1, _p(g), _p(y), _p(gp), g.numel(), _stream())
+            g = gp
+        gw = grad_like(w)
+        dw3x3_wgrad(x, g, gw, None, C, B, C, H, W)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            dw3x3(g, w, None, C, gx, B, C, H, W, flip=True)
+        return gx, gw, None
+
+
+class UnaryFn(torch.autograd.Function):
+    """kind 'leaky': LeakyReLU(0.2); kind 'sigmoid'"""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        _check(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        lib().call("cidnet_elementwise", 0 if kind == "leaky" else 2, _p(x), None, _p(y), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _c(g)
+        gx = torch.empty_like(y)
+        lib().call("cidnet_elementwise", 1 if ctx.kind == "leaky" else 3, _p(g), _p(y), _p(gx), y.numel(), _stream())
+        return gx, None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """dense 3x3, zero pad 1, bias-free (noise_fusion[0], net/CIDNet_TNSM.py:96-98)"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _check(x, w)
+        x = _c(x)
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        y = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
+        conv3x3(x, w, y, B, Co, Ci, H, W, 9 * Ci, 9)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        g = _c(g)
+        gw = grad_like(w)
+        conv3x3_wgrad(g, x, gw, B, Co, Ci, H, W)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            conv3x3(g, w, gx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True)
+        return gx, gw
+
+
+# --------------------------------------------------------------------------------------------
+# K14: TNSM-specific ops
+# --------------------------------------------------------------------------------------------
+class NoiseMapFn(torch.autograd.Function):
+    """DynamicNoiseMap.forward (net/TNSM.py:37-57) -> (B,1,H,W): global avg/max pool, the two tiny FCs
+    and sigmoid, folded with noise_branch[2] and final_conv into one per-sample row vector applied to
+    t = leaky(dw3x3(x))."""
+
+    @staticmethod
+    def forward(ctx, x, w_fc1, w_fc2, w_dw, w_pw, w_final):
+        _check(x, w_fc1, w_fc2, w_dw, w_pw, w_final)
+        x = _c(x)
+        B, C, H, W = x.shape
+        HW = H * W
+        R = w_fc1.shape[0]
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        avg, mx = torch.empty((B, C), **f32), torch.empty((B, C), **f32)
+        amax = torch.empty((B, C), device=dev, dtype=torch.int32)
+        lib().call("cidnet_global_pool_fwd", _p(x), _p(avg), _p(mx), _p(amax), B, C, HW, _stream())
+        hsum, gf, vrow = torch.empty((B, R, 3), **f32), torch.empty((B, C), **f32), torch.empty((B, C), **f32)
+        lib().call("cidnet_noise_global_fwd", _p(avg), _p(mx), _p(w_fc1), _p(w_fc2), _p(w_pw), _p(w_final), _p(hsum), _p(gf),
+                   _p(vrow), B, C, R, _stream())
+        t = torch.empty_like(x)
+        dw3x3(x, w_dw, None, C, t, B, C, H, W)
+        lib().call("cidnet_elementwise", 0, _p(t), None, _p(t), t.numel(), _stream())
+        nm = torch.empty((B, 1, H, W), **f32)
+        lib().call("cidnet_rowdot_sigmoid_fwd", _p(t), _p(vrow), _p(nm), B, C, HW, _stream())
+        ctx.save_for_backward(x, w_fc1, w_fc2, w_dw, w_pw, w_final, avg, mx, amax, hsum, gf, vrow, t, nm)
+        return nm
+
+    @staticmethod
+    def backward(ctx, gnm):
+        x, w_fc1, w_fc2, w_dw, w_pw, w_final, avg, mx, amax, hsum, gf, vrow, t, nm = ctx.saved_tensors
+        B, C, H, W = x.shape
+        HW = H * W
+        R = w_fc1.shape[0]
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        gnm = _c(gnm)
+        gt = torch.empty_like(t)
+        gv = torch.empty((B, C), **f32)
+        lib().call("cidnet_rowdot_sigmoid_bwd", _p(gnm), _p(nm), _p(t), _p(vrow), _p(gt), _p(gv), B, C, HW, _stream())
+        # t = leaky(dw(x))
+        lib().call("cidnet_elementwise", 1, _p(gt), _p(t), _p(gt), gt.numel(), _stream())
+        g_dw = grad_like(w_dw)
+        dw3x3_wgrad(x, gt, g_dw, None, C, B, C, H, W)
+        gx = torch.empty_like(x)
+        dw3x3(gt, w_dw, None, C, gx, B, C, H, W, flip=True)
+        # global branch
+        gW1_b, gW2_b = torch.empty((B, R, C), **f32), torch.empty((B, C, R), **f32)
+        gWn_b, gwf_b = torch.empty((B, C, C), **f32), torch.empty((B, C), **f32)
+        gavg, gmx = torch.empty((B, C), **f32), torch.empty((B, C), **f32)
+        lib().call("cidnet_noise_global_bwd", _p(avg), _p(mx), _p(w_fc1), _p(w_fc2), _p(w_pw), _p(w_final), _p(hsum), _p(gf),
+                   _p(gv), _p(gW1_b), _p(gW2_b), _p(gWn_b), _p(gwf_b), _p(gavg), _p(gmx), B, C, R, _stream())
+        g_fc1, g_fc2, g_pw, g_final = grad_like(w_fc1), grad_like(w_fc2), grad_like(w_pw), grad_like(w_final)
+        for part, out, n in ((gW1_b, g_fc1, R * C), (gW2_b, g_fc2, C * R), (gWn_b, g_pw, C * C), (gwf_b, g_final, C)):
+            lib().call("cidnet_sum_rows", _p(part), B, n, _p(out), _stream())
+        gpool = torch.empty_like(x)
+        lib().call("cidnet_global_pool_bwd", _p(gavg), _p(gmx), _p(amax), _p(gpool), B, C, HW, _stream())
+        lib().call("cidnet_add", _p(gx), _p(gpool), _p(gx), gx.numel(), _stream())
+        return gx, g_fc1, g_fc2, g_dw, g_pw, g_final
+
+
+class NoiseCABResidualFn(torch.autograd.Function):
+    """out = x_res + NoiseAwareAttentionCABStyle(xn, yn, noise_map) (net/TNSM.py:83-128): CAB without the
+    L2 normalisation, value modulated by sigmoid(conv1x1(noise_map))."""
+
+    @staticmethod
+    def forward(ctx, x_res, xn, yn, nm, temperature, wq, wq_dw, wkv, wkv_dw, w_scaler, wp, heads):
+        _check(x_res, xn, yn, nm, temperature, wq, wq_dw, wkv, wkv_dw, w_scaler, wp)
+        x_res, xn, yn, nm = _c(x_res), _c(xn), _c(yn), _c(nm)
+        B, C, H, W = xn.shape
+        HW = H * W
+        dev = xn.device
+        ch = C // heads
+        f32 = dict(device=dev, dtype=torch.float32)
+        qkv0 = torch.empty((B, 3 * C, H, W), **f32)
+        pw_conv(xn, 0, C * HW, wq, 0, 0, C, 1, qkv0, 0, 3 * C * HW, B, C, C, HW)
+        pw_conv(yn, 0, C * HW, wkv, 0, 0, C, 1, qkv0, C * HW, 3 * C * HW, B, 2 * C, C, HW)
+        qkv = torch.empty_like(qkv0)
+        dw3x3(qkv0, wq_dw, wkv_dw, C, qkv, B, 3 * C, H, W)
+        attn = torch.empty((B, heads, ch, ch), **f32)
+        shat = torch.empty_like(attn)
+        nq, nk = torch.empty((B, C), **f32), torch.empty((B, C), **f32)
+        M = torch.empty((B, C, C), **f32)
+        n = _raw("cidnet_attn_gram_ws_floats", B, C, heads, HW)
+        ws = _ws(n, dev)
+        lib().call("cidnet_attn_fwd", _p(qkv), _p(temperature), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(M), _p(ws),
+                   ws.numel(), B, C, heads, HW, 0, _stream())
+        vmod = torch.empty((B, C, H, W), **f32)
+        lib().call("cidnet_modulate_fwd", _po(qkv, 2 * C * HW), 3 * C * HW, _p(nm), _p(w_scaler), _p(vmod), B, C, HW, _stream())
+        out = torch.empty_like(x_res)
+        pw_conv(vmod, 0, C * HW, M, 0, C * C, C, 1, out, 0, C * HW, B, C, C, HW, res=x_res, r_bs=C * HW)
+        ctx.save_for_backward(xn, yn, nm, qkv0, qkv, vmod, attn, shat, nq, nk, M, temperature, wq, wq_dw, wkv, wkv_dw, w_scaler, wp)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (xn, yn, nm, qkv0, qkv, vmod, attn, shat, nq, nk, M, temperature, wq, wq_dw, wkv, wkv_dw, w_scaler,
+         wp) = ctx.saved_tensors
+        heads = ctx.heads
+        B, C, H, W = xn.shape
+        HW = H * W
+        dev = xn.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        g = _c(g)
+        dqkv = torch.empty_like(qkv)
+        dvm = torch.empty_like(vmod)
+        pw_conv(g, 0, C * HW, M, 0, C * C, 1, C, dvm, 0, C * HW, B, C, C, HW)
+        dM = torch.empty_like(M)
+        pw_wgrad(g, 0, C * HW, vmod, 0, C * HW, dM, 0, C, B, C, C, HW, per_sample=True)
+        # v' = v * sigmoid(ws * nm)
+        gnm = torch.empty_like(nm)
+        nws = _raw("cidnet_modulate_bwd_ws_floats", B, C, HW)
+        part = torch.empty(nws, **f32)
+        lib().call("cidnet_modulate_bwd", _po(qkv, 2 * C * HW), 3 * C * HW, _p(nm), _p(w_scaler), _p(dvm), _po(dqkv, 2 * C * HW),
+                   3 * C * HW, _p(gnm), _p(part), B, C, HW, _stream())
+        g_ws = grad_like(w_scaler)
+        lib().call("cidnet_sum_rows", _p(part), nws // C, C, _p(g_ws), _stream())
+        dwp_b = torch.empty_like(M)
+        dT_b = torch.empty((B, heads), **f32)
+        wqk = torch.empty((B, 2 * C, 2 * C), **f32)
+        lib().call("cidnet_attn_bwd", _p(dM), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(temperature), _p(dwp_b), _p(dT_b),
+                   _p(wqk), B, C, heads, 0, _stream())
+        g_wp = grad_like(wp)
+        lib().call("cidnet_sum_rows", _p(dwp_b), B, C * C, _p(g_wp), _stream())
+        g_T = grad_like(temperature)
+        lib().call("cidnet_sum_rows", _p(dT_b), B, heads, _p(g_T), _stream())
+        pw_conv(qkv, 0, 3 * C * HW, wqk, 0, 4 * C * C, 2 * C, 1, dqkv, 0, 3 * C * HW, B, 2 * C, 2 * C, HW)
+        g_wq_dw, g_wkv_dw = grad_like(wq_dw), grad_like(wkv_dw)
+        dw3x3_wgrad(qkv0, dqkv, g_wq_dw, g_wkv_dw, C, B, 3 * C, H, W)
+        dqkv0 = torch.empty_like(qkv0)
+        dw3x3(dqkv, wq_dw, wkv_dw, C, dqkv0, B, 3 * C, H, W, flip=True)
+        g_wq, g_wkv = grad_like(wq), grad_like(wkv)
+        pw_wgrad(dqkv0, 0, 3 * C * HW, xn, 0, C * HW, g_wq, 0, C, B, C, C, HW)
+        pw_wgrad(dqkv0, C * HW, 3 * C * HW, yn, 0, C * HW, g_wkv, 0, C, B, 2 * C, C, HW)
+        dxn = torch.empty_like(xn)
+        pw_conv(dqkv0, 0, 3 * C * HW, wq, 0, 0, 1, C, dxn, 0, C * HW, B, C, C, HW)
+        dyn = torch.empty_like(yn)
+        pw_conv(dqkv0, C * HW, 3 * C * HW, wkv, 0, 0, 1, C, dyn, 0, C * HW, B, C, 2 * C, HW)
+        return g, dxn, dyn, gnm, g_T, g_wq, g_wq_dw, g_wkv, g_wkv_dw, g_ws, g_wp, None
+
+
+class BlendFn(torch.autograd.Function):
+    """nm * a + (1 - nm) * d with nm (B,1,H,W) broadcast over channels (net/TNSM.py:165-166)."""
+
+    @staticmethod
+    def forward(ctx, a, d, nm):
+        _check(a, d, nm)
+        a, d, nm = _c(a), _c(d), _c(nm)
+        B, C, H, W = a.shape
+        out = torch.empty_like(a)
+        lib().call("cidnet_blend_fwd", _p(a), _p(d), _p(nm), _p(out), B, C, H * W, _stream())
+        ctx.save_for_backward(a, d, nm)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, d, nm = ctx.saved_tensors
+        B, C, H, W = a.shape
+        g = _c(g)
+        ga, gd, gnm = torch.empty_like(a), torch.empty_like(d), torch.empty_like(nm)
+        lib().call("cidnet_blend_bwd", _p(a), _p(d), _p(nm), _p(g), _p(ga), _p(gd), _p(gnm), B, C, H * W, _stream())
+        return ga, gd, gnm
+
+
+class ResizeCatFn(torch.autograd.Function):
+    """cat([F.interpolate(m, (H,W), 'bilinear', align_corners=False) for m in maps], 1)
+    (net/CIDNet_TNSM.py:252-262); each map is resized straight into its channel slice."""
+
+    @staticmethod
+    def forward(ctx, H, W, *maps):
+        _check(*maps)
+        maps = [_c(m) for m in maps]
+        B = maps[0].shape[0]
+        ctot = sum(m.shape[1] for m in maps)
+        out = torch.empty((B, ctot, H, W), device=maps[0].device, dtype=torch.float32)
+        off = 0
+        for m in maps:
+            c, hi, wi = m.shape[1:]
+            lib().call("cidnet_resize_bilinear_fwd", _p(m), _po(out, off * H * W), ctot * H * W, B, c, hi, wi, H, W, _stream())
+            off += c
+        ctx.shapes = [tuple(m.shape) for m in maps]
+        ctx.hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.hw
+        g = _c(g)
+        ctot = g.shape[1]
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            B, c, hi, wi = shp
+            gm = torch.empty(shp, device=g.device, dtype=torch.float32)
+            lib().call("cidnet_resize_bilinear_bwd", _po(g, off * H * W), ctot * H * W, _p(gm), B, c, hi, wi, H, W, _stream())
+            outs.append(gm)
+            off += c
+        return (None, None, *outs)

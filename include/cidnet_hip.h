@@ -102,6 +102,10 @@ int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, 
 long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W);
 int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw2, int csplit,
                        float* ws, long ws_floats, int B, int C, int H, int W, void* stream);
+/* fused backward: gin = dw3x3(gout, flipped) [+ addend] and gw in ONE pass over (in, gout) */
+int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const float* w2, int csplit,
+                     const float* addend, float* gin, float* gw1, float* gw2, float* ws,
+                     long ws_floats, int B, int C, int H, int W, void* stream);
 /* g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2);  u: (B,2h,H,W) = [u1;u2], g: (B,h,H,W). */
 int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h,
                         int H, int W, void* stream);
@@ -139,16 +143,17 @@ int cidnet_add(const float* a, const float* b, float* y, long n, void* stream);
 /* ---- K7: channel attention of CAB  (net/LCA.py:26-38) -------------------------------------------
  * qkv: (B,3C,HW) = [q;k;v] after the depthwise convs.  Produces attn = softmax(normalize(q)
  * normalize(k)^T * temperature) per (b,head), the normalised logits shat, the row norms nq,nk (B,C)
- * and M[b] = Wp * blockdiag(attn[b]) (B,C,C) so that project_out(attn @ v) = M[b] * v[b]. */
+ * and M[b] = Wp * blockdiag(attn[b]) (B,C,C) so that project_out(attn @ v) = M[b] * v[b].
+ * normalize = 0 gives the TNSM attention (net/TNSM.py:98-104): raw q k^T logits, no L2 normalisation. */
 long cidnet_attn_gram_ws_floats(int B, int C, int heads, long HW);
 int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp, float* attn,
                     float* shat, float* nq, float* nk, float* M, float* ws, long ws_floats, int B,
-                    int C, int heads, long HW, void* stream);
+                    int C, int heads, long HW, int normalize, void* stream);
 /* From dM (B,C,C): per-sample dWp_b (B,C,C), dT_b (B,heads), and Wqk (B,2C,2C) with
  * [dq;dk][b] = Wqk[b] * [q;k][b]  (softmax + L2-normalisation backward folded). */
 int cidnet_attn_bwd(const float* dM, const float* Wp, const float* attn, const float* shat,
                     const float* nq, const float* nk, const float* temperature, float* dWp_b,
-                    float* dT_b, float* Wqk, int B, int C, int heads, void* stream);
+                    float* dT_b, float* Wqk, int B, int C, int heads, int normalize, void* stream);
 /* out[i] = sum_r in[r*n + i] (fixed order) */
 int cidnet_sum_rows(const float* in, int n_red, long n, float* out, void* stream);
 
@@ -172,6 +177,50 @@ long cidnet_sa_bwd_ws_floats(int B, int H, int W);
 int cidnet_sa_bwd(const float* x, const float* w, const float* stats, const int* amax,
                   const float* att, const float* g, float* gx, float* gw, float* ws, long ws_floats,
                   int B, int C, int H, int W, void* stream);
+
+/* ---- K14: pieces of the TNSM variant (net/TNSM.py) ----------------------------------------------
+ * adaptive avg + max pool to 1x1 (:39-40); amax = flat index of the maximum per (b,c) plane */
+int cidnet_global_pool_fwd(const float* x, float* avg, float* mx, int* amax, int B, int C, long HW,
+                           void* stream);
+int cidnet_global_pool_bwd(const float* gavg, const float* gmx, const int* amax, float* gx, int B, int C,
+                           long HW, void* stream);
+/* DynamicNoiseMap global branch (:43-47) folded with noise_branch[2] (Wn) and final_conv (wf):
+ * gf = sigmoid(W2 (relu(W1 avg) + relu(W1 mx))), vrow[k] = sum_c wf[c] gf[c] Wn[c][k], so that
+ * noise_map = sigmoid(vrow . leaky(dw3x3(x))).  hsum: (B,R,3) saved for the backward. */
+int cidnet_noise_global_fwd(const float* avg, const float* mx, const float* W1, const float* W2,
+                            const float* Wn, const float* wf, float* hsum, float* gf, float* vrow,
+                            int B, int C, int R, void* stream);
+/* per-sample parameter-gradient partials (sum over B with cidnet_sum_rows) + gavg, gmx (B,C) */
+int cidnet_noise_global_bwd(const float* avg, const float* mx, const float* W1, const float* W2,
+                            const float* Wn, const float* wf, const float* hsum, const float* gf,
+                            const float* gvrow, float* gW1_b, float* gW2_b, float* gWn_b, float* gwf_b,
+                            float* gavg, float* gmx, int B, int C, int R, void* stream);
+/* mode 0: y = leaky_relu(a, 0.2); 1: y = a * (b > 0 ? 1 : 0.2) (a = grad, b = forward output);
+ * 2: y = sigmoid(a); 3: y = a * b * (1 - b) (a = grad, b = forward output) */
+int cidnet_elementwise(int mode, const float* a, const float* b, float* y, long n, void* stream);
+/* nm[b][p] = sigmoid(sum_c v[b][c] t[b][c][p]) and its backward (gt (B,C,HW), gv (B,C)) */
+int cidnet_rowdot_sigmoid_fwd(const float* t, const float* v, float* nm, int B, int C, long HW,
+                              void* stream);
+int cidnet_rowdot_sigmoid_bwd(const float* gnm, const float* nm, const float* t, const float* v,
+                              float* gt, float* gv, int B, int C, long HW, void* stream);
+/* v' = v * sigmoid(ws[c] * nm) (:103-112); vin may be a channel slice (batch stride vin_bs) */
+int cidnet_modulate_fwd(const float* vin, long vin_bs, const float* nm, const float* ws, float* vout,
+                        int B, int C, long HW, void* stream);
+long cidnet_modulate_bwd_ws_floats(int B, int C, long HW);
+int cidnet_modulate_bwd(const float* vin, long vin_bs, const float* nm, const float* ws,
+                        const float* gvout, float* gvin, long gvin_bs, float* gnm, float* gws_part,
+                        int B, int C, long HW, void* stream);
+/* out = nm * a + (1 - nm) * d (AdaptiveFilter :165-166) and its backward */
+int cidnet_blend_fwd(const float* a, const float* d, const float* nm, float* out, int B, int C, long HW,
+                     void* stream);
+int cidnet_blend_bwd(const float* a, const float* d, const float* nm, const float* g, float* ga,
+                     float* gd, float* gnm, int B, int C, long HW, void* stream);
+/* F.interpolate(bilinear, align_corners=False) (CIDNet_TNSM.py:258); dst / gdst may be channel
+ * slices of a wider tensor (batch stride in floats) */
+int cidnet_resize_bilinear_fwd(const float* src, float* dst, long dst_bs, int B, int C, int Hi, int Wi,
+                               int Ho, int Wo, void* stream);
+int cidnet_resize_bilinear_bwd(const float* gdst, long gdst_bs, float* gsrc, int B, int C, int Hi,
+                               int Wi, int Ho, int Wo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -418,6 +418,15 @@ def gen_tnsm():
         out[f"model_g.{n}"] = prm.grad.numpy()
     assert all(n.startswith(("I_LCA5.", "I_TNSM5.")) for n in dead), dead
     out["model_dead"] = np.array(dead)
+    # fp64 ground truth of the same gradients: TNSM's un-normalised attention saturates its softmax, so the
+    # reference's own fp32 gradients are ~2e-3 (relative to each tensor's max) away from the exact ones;
+    # the GPU parity test measures its error against fp64 and compares it with the reference's own error
+    p64 = O.params_to(p, dtype=torch.float64, requires_grad=True)
+    y64, f64 = O.cidnet_tnsm_forward(p64, x.double())
+    ((y64 - gt.double()).abs().mean() + 0.1 * f64.mean()).backward()
+    for n, v in p64.items():
+        if v.grad is not None:
+            out[f"model_g64.{n}"] = v.grad.numpy().astype(np.float32)
     print(f"  ok  CIDNet_TNSM grads: worst rel-to-max diff {worst:.2e}; {len(dead)} dead tensors (I_LCA5.*, I_TNSM5.*)")
     assert worst < 1e-4
     np.savez_compressed(os.path.join(GOLD, "tnsm.npz"), **out)

@@ -110,3 +110,19 @@ def test_mssa_matches_reference(golden):
     (out - _t(g["model_gt"])).abs().mean().backward()
     for n, v in p.items():
         _close(v.grad, g[f"model_g.{n}"], rel=1e-5)
+
+
+def test_tnsm_matches_reference(golden):
+    """TNSM variant (net/TNSM.py, net/CIDNet_TNSM.py): 468-tensor model, (rgb, fused_noise) in training mode"""
+    g = golden("tnsm")
+    p = O.params_to(O.make_params(5, channels=(12, 12, 24, 48), variant="tnsm"), requires_grad=True)
+    assert len(p) == 468
+    rgb, fz = O.cidnet_tnsm_forward(p, _t(g["model_x"]))
+    assert torch.equal(rgb.detach(), _t(g["model_out"])) and torch.equal(fz.detach(), _t(g["model_noise"]))
+    ((rgb - _t(g["model_gt"])).abs().mean() + 0.1 * fz.mean()).backward()
+    dead = set(g["model_dead"].tolist())
+    for n, v in p.items():
+        if n in dead:
+            assert v.grad is None
+        else:
+            _close(v.grad, g[f"model_g.{n}"], rel=1e-5)

@@ -30,6 +30,8 @@ if __name__ == "__main__":
     shapes = [(8, 190, 36, 60000), (8, 36, 190, 60000), (8, 36, 36, 60000), (8, 36, 95, 60000), (8, 72, 72, 15000),
               (8, 382, 72, 15000), (8, 766, 144, 3750), (8, 144, 766, 3750), (8, 36, 36, 240000)]
     for sh in shapes:
+        mts = " ".join(f"MT{mt}:{run(*sh, flags=(512 << 8) | (mt << 28))[0]:.1f}" for mt in (1, 2, 3, 4))
+        print(f"  forced channel tiles {sh}: {mts}")
         tb = " ".join(f"{tbk}:{run(*sh, flags=(tbk << 8))[0]:.1f}" for tbk in (256, 512, 768, 1024, 1536, 2048, 4096))
         print(f"  target-blocks sweep {sh}: {tb}")
         r = [run(*sh, flags=f | (1024 << 8)) for f in (0, 1, 2, 3, 8, 9, 4)]
