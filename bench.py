@@ -155,7 +155,7 @@ def main():
                 print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
         roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad)",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                 "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
                 "share_of_step_kernel_time": round(c3_ms / tot, 3) if tot else None}
 
@@ -176,6 +176,17 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_conv3_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction);
+    counters cannot be read from inside this process, so this is null if the summary is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv3_traffic.json")))
+        return int(d["avg_hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def usable_cores():

@@ -21,6 +21,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kR = 2;      // output rows per wave
 constexpr int kKC = 36;    // input channels staged per chunk (9 k-groups)
+int g_c3_dbg = 0;
 
 struct C3Args {
   const float* X; long x_bs;
@@ -31,6 +32,7 @@ struct C3Args {
   int replicate;   // border mode of the input
   int nmb;         // number of m-blocks (blockIdx.z = b*nmb + mb)
   int tpb;         // row tiles per block (launcher)
+  int dbg;         // timing-study switches (0 in production): 1 no stores, 2 no window loads, 4 no LDS weight reads
 };
 
 struct Win6 {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
         Win6 win[kR + 2];
 #pragma unroll
         for (int iy = 0; iy < kR + 2; ++iy) win[iy] = nxt[iy];
-        if (g + 1 < ng) {
+        if (g + 1 < ng && !(a.dbg & 2)) {
           const float* plane = Xb + (long)min(kc0 + 4 * (g + 1) + j, a.K - 1) * HW;
 #pragma unroll
           for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[((g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
+          for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[(((a.dbg & 4) ? 0 : g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
 #pragma unroll
         for (int iy = 0; iy < kR + 2; ++iy)
 #pragma unroll
@@ -177,6 +179,15 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
     }
 
     if (x0 >= W || !wave_live) continue;
+    if (a.dbg & 1) {
+#pragma unroll
+      for (int r = 0; r < kR; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[r][mt][e]));
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
       const int y = yw + r;
@@ -455,12 +466,14 @@ using namespace cidnet;
 
 extern "C" {
 
+void cidnet_debug_c3_flags(int flags) { g_c3_dbg = flags; }
+
 int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, int replicate, float* Y,
                    long y_bs, int B, int M, int K, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(X && Wt && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
   C3Args a{};
   a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs;
-  a.M = M; a.K = K; a.H = H; a.W = W; a.flip = flip; a.replicate = replicate;
+  a.M = M; a.K = K; a.H = H; a.W = W; a.flip = flip; a.replicate = replicate; a.dbg = g_c3_dbg;
   const int T = (M + 15) / 16;
   const int nblk = (T + 2) / 3;
   const int MT = (T + nblk - 1) / nblk;

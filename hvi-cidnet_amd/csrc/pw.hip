@@ -370,6 +370,135 @@ bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
   return false;
 }
 
+// Split-K variant for small planes (e.g. 50x75 = 3750 pixels) with large K: too few 256-pixel tiles
+// exist to fill 256 CUs, so a block takes ONE 64-pixel group and its four waves split the K loop
+// (k-step s goes to wave s % 4).  Each wave keeps its quarter of the weight panel in registers
+// (KSW x MT fragments) across the `tpb` pixel groups the block walks; per group the four partial
+// accumulators are summed through LDS and each thread stores one float4.  No weight staging, no
+// barrier inside the K loop.  EPI: 0 plain, 1 + residual.
+template <int MT, int EPI, int KSW>
+__global__ __launch_bounds__(kThreads) void pw_conv_splitk_kernel(PwArgs a) {
+  extern __shared__ float red[];                 // [4 waves][MT*16][64]
+  constexpr int MB = 16 * MT;
+  constexpr int D = KSW >= 8 ? 8 : KSW;          // prefetch distance (k-steps of this wave)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, j = lane >> 4;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * MB;
+  const long HW = a.HW;
+  const float* Xb = a.X + (long)b * a.x_bs;
+  const float* Wb = a.Wt + (long)b * a.w_bs;
+  const long ngroups = (HW + 63) / 64;
+  const long g_beg = (long)blockIdx.x * a.tpb;
+  const long g_end = min(g_beg + a.tpb, ngroups);
+  const int klast = a.K - 1;
+
+  float areg[KSW][MT];
+#pragma unroll
+  for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + c, k = 4 * (wave + 4 * ks) + j;
+      areg[ks][mt] = (m < a.M && k < a.K) ? Wb[(long)m * a.w_ms + (long)k * a.w_ks] : 0.f;
+    }
+
+  for (long grp = g_beg; grp < g_end; ++grp) {
+    const long p0 = grp * 64 + 4 * c;
+    const bool inside = p0 + 3 < HW;             // lanes straddling / past the end take checked loads
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto xload = [&](int ks) -> f32x4 {
+      const float* row = Xb + (long)min(4 * (wave + 4 * ks) + j, klast) * HW;
+      return inside ? load4u(row + p0) : load_px4(row, p0, HW, true);
+    };
+    f32x4 ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = xload(d);
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) {
+      const f32x4 xc = ring[ks % D];
+      if (ks + D < KSW) ring[ks % D] = xload(ks + D);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks][mt], xc[e], acc[mt][e], 0, 0, 0);
+    }
+    // cross-wave sum
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[((wave * MT * 16) + (mt * 4 + e) * 4 + reg) * 64 + lane] = acc[mt][e][reg];
+    __syncthreads();
+    const int reg = wave;                        // thread (reg = tid>>6, lane) owns rows j*4+reg of every m-tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + j * 4 + reg;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = ((mt * 4 + e) * 4 + reg) * 64 + lane;
+        v[e] = (red[idx] + red[MT * 16 * 64 + idx]) + (red[2 * MT * 16 * 64 + idx] + red[3 * MT * 16 * 64 + idx]);
+      }
+      if (m < a.M && p0 < HW) {
+        if (EPI == 1) v += load_px4(a.R + (long)b * a.r_bs + (long)m * HW, p0, HW, true);
+        store_px4(a.Y + (long)b * a.y_bs + (long)m * HW, p0, HW, v);
+      }
+    }
+  }
+}
+
+template <int MT, int EPI, int KSW>
+int launch_pw_splitk(PwArgs a, int B, hipStream_t s) {
+  constexpr int MB = 16 * MT;
+  const long mblocks = (a.M + MB - 1) / MB;
+  const long ngroups = (a.HW + 63) / 64;
+  long tpb = (ngroups * mblocks * B + 1023) / 1024;
+  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  a.tpb = (int)tpb;
+  dim3 grid((unsigned)((ngroups + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
+  const size_t lds = (size_t)4 * MT * 16 * 64 * sizeof(float);
+  hipLaunchKernelGGL((pw_conv_splitk_kernel<MT, EPI, KSW>), grid, dim3(kThreads), lds, s, a);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+// small-plane / large-K dispatch; -> true if handled.  A wave can keep at most 24 k-steps x 3 channel
+// tiles of weights in registers at 2 waves/SIMD, i.e. K <= 384 per launch: larger K runs as two launches,
+// the second accumulating into Y through the residual epilogue.
+template <int EPI>
+int splitk_one(const PwArgs& a, int B, hipStream_t s) {
+  const int ksw = (a.K + 15) / 16;               // k-steps per wave
+  const int T = (a.M + 15) / 16;
+  const int MT = T >= 3 ? 3 : T;
+#define SK(mt, kk) return launch_pw_splitk<mt, EPI, kk>(a, B, s);
+  if (MT == 1) { if (ksw <= 9) SK(1, 9) if (ksw <= 18) SK(1, 18) SK(1, 24) }
+  if (MT == 2) { if (ksw <= 9) SK(2, 9) if (ksw <= 18) SK(2, 18) SK(2, 24) }
+  if (ksw <= 9) SK(3, 9) if (ksw <= 18) SK(3, 18) SK(3, 24)
+#undef SK
+}
+
+template <int EPI>
+bool try_splitk(const PwArgs& a, int B, hipStream_t s, int* rc) {
+  if (a.HW > 8192 || a.K < 64 || a.K > 768) return false;
+  if (a.K <= 384) { *rc = splitk_one<EPI>(a, B, s); return true; }
+  PwArgs lo = a, hi = a;
+  lo.K = 384;
+  *rc = splitk_one<EPI>(lo, B, s);
+  if (*rc != CIDNET_OK) return true;
+  hi.K = a.K - 384;
+  hi.X = a.X + 384L * a.HW;
+  hi.Wt = a.Wt + 384L * a.w_ks;
+  hi.R = a.Y; hi.r_bs = a.y_bs;                  // accumulate: Y += A[:, 384:] * X[384:]
+  *rc = splitk_one<1>(hi, B, s);
+  return true;
+}
+
 template <int MT, int EPI>
 int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT;
@@ -423,6 +552,10 @@ int launch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
 
 int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
   a.dbg = g_pw_dbg;
+  if (epi != 2 && !(g_pw_dbg & 16)) {
+    int rc = CIDNET_OK;
+    if (epi == 0 ? try_splitk<0>(a, B, s, &rc) : try_splitk<1>(a, B, s, &rc)) return rc;
+  }
   const int T = (a.M + 15) / 16;
   const int ks = (a.K + 3) / 4;
   int MT;

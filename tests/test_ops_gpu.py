@@ -23,7 +23,9 @@ def close(a, b, rel=2e-5, what=""):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 36, 36, 8, 12), (1, 95, 36, 13, 17), (2, 36, 190, 20, 30), (1, 144, 766, 5, 15),
                                          (2, 383, 144, 10, 15), (1, 3, 7, 3, 3), (2, 72, 72, 100, 150),
-                                         (8, 36, 190, 200, 300), (4, 36, 36, 400, 600), (8, 72, 36, 200, 300)])  # multi-tile blocks
+                                         (8, 36, 190, 200, 300), (4, 36, 36, 400, 600), (8, 72, 36, 200, 300),  # multi-tile blocks
+                                         (8, 766, 144, 50, 75), (8, 144, 766, 50, 75), (2, 288, 288, 50, 75), (3, 383, 144, 50, 75),
+                                         (2, 100, 72, 9, 13)])  # small planes: split-K kernel, K > 384 in two passes
 def test_pw_conv_fwd_dgrad_wgrad(dev, B, Ci, Co, H, W):
     from hvi_cidnet_amd import ops
     x, w, r = rnd(1, (B, Ci, H, W)), rnd(2, (Co, Ci, 1, 1), 0.3), rnd(3, (B, Co, H, W))
