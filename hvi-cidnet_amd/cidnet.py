@@ -82,6 +82,31 @@ class CIDNet(nn.Module, _HubMixin):
         # dead block is not executed here.
         return i_dec3
 
+    # ---- two-stream execution: the I branch and the HV branch of every stage are independent ----
+    two_streams = True
+
+    def _par(self, f_i, f_hv, shared):
+        """Run f_i on the current stream and f_hv on a side stream, then join.  `shared` = tensors read by
+        both (allocator bookkeeping for cross-stream use)."""
+        if not (self.two_streams and shared[0].is_cuda):
+            return f_i(), f_hv()
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != shared[0].device:
+            side = torch.cuda.Stream(device=shared[0].device)
+            object.__setattr__(self, "_side_stream", side)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out_hv = f_hv()
+        out_i = f_i()
+        main.wait_stream(side)
+        for t in shared:
+            t.record_stream(side)
+        for t in (out_hv if isinstance(out_hv, (tuple, list)) else (out_hv,)):
+            if isinstance(t, torch.Tensor):
+                t.record_stream(main)
+        return out_i, out_hv
+
     def forward(self, x):
         if x.shape[2] % 8 or x.shape[3] % 8:
             raise RuntimeError(f"CIDNet: H and W must be multiples of 8 (got {tuple(x.shape[2:])}); the reference "
@@ -89,46 +114,40 @@ class CIDNet(nn.Module, _HubMixin):
         hvi = self.trans.HVIT(x)
         i = hvi[:, 2:3, :, :].contiguous()
         # low
-        i_enc0 = self.IE_block0(i)
-        i_enc1 = self.IE_block1(i_enc0)
-        hv_0 = self.HVE_block0(hvi)
-        hv_1 = self.HVE_block1(hv_0)
+        (i_enc0, i_enc1), (hv_0, hv_1) = self._par(
+            lambda: (lambda e0: (e0, self.IE_block1(e0)))(self.IE_block0(i)),
+            lambda: (lambda h0: (h0, self.HVE_block1(h0)))(self.HVE_block0(hvi)), (hvi, i))
         i_jump0 = i_enc0
         hv_jump0 = hv_0
 
-        i_enc2 = self.I_LCA1(i_enc1, hv_1)
-        hv_2 = self.HV_LCA1(hv_1, i_enc1)
+        i_enc2, hv_2 = self._par(lambda: self.I_LCA1(i_enc1, hv_1), lambda: self.HV_LCA1(hv_1, i_enc1), (i_enc1, hv_1))
         v_jump1 = i_enc2
         hv_jump1 = hv_2
-        i_enc2 = self.IE_block2(i_enc2)
-        hv_2 = self.HVE_block2(hv_2)
+        i_enc2, hv_2 = self._par(lambda: self.IE_block2(v_jump1), lambda: self.HVE_block2(hv_jump1), (v_jump1, hv_jump1))
 
-        v_jump2 = self.I_LCA2(i_enc2, hv_2)
-        hv_jump2 = self.HV_LCA2(hv_2, i_enc2)
-        i_enc3 = self.IE_block3(i_enc2)      # reference quirk: level-3 encoders take the PRE-LCA2
-        hv_3 = self.HVE_block3(hv_2)         # tensors (net/CIDNet.py:94-95)
+        # reference quirk: level-3 encoders take the PRE-LCA2 tensors (net/CIDNet.py:94-95)
+        (v_jump2, i_enc3), (hv_jump2, hv_3) = self._par(
+            lambda: (self.I_LCA2(i_enc2, hv_2), self.IE_block3(i_enc2)),
+            lambda: (self.HV_LCA2(hv_2, i_enc2), self.HVE_block3(hv_2)), (i_enc2, hv_2))
 
-        i_enc4 = self.I_LCA3(i_enc3, hv_3)
-        hv_4 = self.HV_LCA3(hv_3, i_enc3)
+        i_enc4, hv_4 = self._par(lambda: self.I_LCA3(i_enc3, hv_3), lambda: self.HV_LCA3(hv_3, i_enc3), (i_enc3, hv_3))
+        i_dec4, hv_4b = self._par(lambda: self.I_LCA4(i_enc4, hv_4), lambda: self.HV_LCA4(hv_4, i_enc4), (i_enc4, hv_4))
 
-        i_dec4 = self.I_LCA4(i_enc4, hv_4)
-        hv_4 = self.HV_LCA4(hv_4, i_enc4)
+        i_dec3, hv_3 = self._par(lambda: self._gate("sa_i3", self.ID_block3(i_dec4, v_jump2)),
+                                 lambda: self._gate("sa_hv3", self.HVD_block3(hv_4b, hv_jump2)),
+                                 (i_dec4, hv_4b, v_jump2, hv_jump2))
+        i_dec2, hv_2 = self._par(lambda: self._i_dec2_input(i_dec3, hv_3), lambda: self.HV_LCA5(hv_3, i_dec3), (i_dec3, hv_3))
 
-        hv_3 = self._gate("sa_hv3", self.HVD_block3(hv_4, hv_jump2))
-        i_dec3 = self._gate("sa_i3", self.ID_block3(i_dec4, v_jump2))
-        i_dec2 = self._i_dec2_input(i_dec3, hv_3)
-        hv_2 = self.HV_LCA5(hv_3, i_dec3)
+        i_dec2, hv_2 = self._par(lambda: self._gate("sa_i2", self.ID_block2(i_dec2, v_jump1)),
+                                 lambda: self._gate("sa_hv2", self.HVD_block2(hv_2, hv_jump1)),
+                                 (i_dec2, hv_2, v_jump1, hv_jump1))
 
-        hv_2 = self._gate("sa_hv2", self.HVD_block2(hv_2, hv_jump1))
-        i_dec2 = self._gate("sa_i2", self.ID_block2(i_dec2, v_jump1))
+        i_dec1, hv_1 = self._par(lambda: self.I_LCA6(i_dec2, hv_2), lambda: self.HV_LCA6(hv_2, i_dec2), (i_dec2, hv_2))
 
-        i_dec1 = self.I_LCA6(i_dec2, hv_2)
-        hv_1 = self.HV_LCA6(hv_2, i_dec2)
-
-        i_dec1 = self._gate("sa_i1", self.ID_block1(i_dec1, i_jump0))
-        i_dec0 = self.ID_block0(i_dec1)
-        hv_1 = self._gate("sa_hv1", self.HVD_block1(hv_1, hv_jump0))
-        hv_0 = self.HVD_block0(hv_1)
+        i_dec0, hv_0 = self._par(
+            lambda: self.ID_block0(self._gate("sa_i1", self.ID_block1(i_dec1, i_jump0))),
+            lambda: self.HVD_block0(self._gate("sa_hv1", self.HVD_block1(hv_1, hv_jump0))),
+            (i_dec1, hv_1, i_jump0, hv_jump0))
 
         # cat([hv_0, i_dec0], 1) + hvi -> PHVIT, fused (net/CIDNet.py:119-120)
         return self.trans.PHVIT_residual(hv_0, i_dec0, hvi)

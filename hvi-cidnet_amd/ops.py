@@ -142,8 +142,9 @@ _WS = {}
 
 
 def _ws(n_floats, device):
-    """Stream-ordered scratch buffer (grown on demand, reused by consecutive launches)."""
-    key = (device.type, device.index)
+    """Stream-ordered scratch buffer (grown on demand, reused by consecutive launches); one per stream,
+    because the two CIDNet branches may run on two streams concurrently."""
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < n_floats:
         t = torch.empty(max(int(n_floats), 1 << 20), device=device, dtype=torch.float32)
