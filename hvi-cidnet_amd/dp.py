@@ -70,7 +70,7 @@ class FlatAdam:
 class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, n_buckets: int = 4, loss_fn: Optional[Callable] = None,
-                 process_group=None, use_hip_kernels: bool = True):
+                 process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = False):
         self.model = model
         self.loss_fn = loss_fn or _default_loss
         self.pg = process_group
@@ -80,6 +80,9 @@ class DataParallelTrainer:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.n_buckets = max(1, n_buckets)
         self.use_hip = use_hip_kernels
+        # weight-gradient GEMMs on a third stream: measured neutral once the two branch streams already fill the
+        # GPU (46.6 vs 46.8 ms/step), so it is off by default
+        self.wgrad_stream = wgrad_stream
         self._opt_args = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._ready = False
         self._handles: List = []
@@ -154,10 +157,17 @@ class DataParallelTrainer:
         if self.use_hip:
             from . import ops
             ops.set_grad_arena(self.flat_p, self.flat_g, exclude_ptrs=multi)
+            ops.enable_wgrad_stream(self.wgrad_stream)
         for p in live:
             p.register_post_accumulate_grad_hook(self._on_grad)
         self.opt = FlatAdam(self.flat_p, kernel=self.use_hip, **self._opt_args)
         self._ready = True
+
+    def _join_wgrad_stream(self):
+        """make the current stream wait for the weight-gradient stream (ops._offload_wgrad)"""
+        if self.use_hip:
+            from . import ops
+            torch.cuda.current_stream().wait_stream(ops.wgrad_stream(self.flat_g.device))
 
     def _on_grad(self, p):
         off, n = self._slices[id(p)]
@@ -169,6 +179,7 @@ class DataParallelTrainer:
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and (self.world > 1 or self._force_comm):
             start, cnt, _ = self.buckets[bi]
+            self._join_wgrad_stream()               # the bucket's last weight gradients may still be in flight
             self._handles.append(dist.all_reduce(self.flat_g[start:start + cnt], op=dist.ReduceOp.SUM, group=self.pg,
                                                  async_op=True))
 
@@ -184,6 +195,7 @@ class DataParallelTrainer:
         loss.backward()
         for h in self._handles:
             h.wait()
+        self._join_wgrad_stream()
         self.opt.step(self.flat_g, self.n_live, grad_scale=1.0 / self.world)
         return loss.detach()
 
@@ -198,4 +210,5 @@ class DataParallelTrainer:
         loss.backward()
         for h in self._handles:
             h.wait()
+        self._join_wgrad_stream()
         return loss.detach()

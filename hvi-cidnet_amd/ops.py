@@ -152,6 +152,52 @@ def _ws(n_floats, device):
     return t
 
 
+# Weight-gradient GEMMs feed nothing but the optimizer, so they may run on a third stream and overlap the
+# data-gradient chain.  Only safe when the caller (dp.DataParallelTrainer) waits for that stream before it
+# touches the gradients, and only for single-use parameters written in place into the gradient arena.
+_WG = {"on": False, "streams": {}}
+
+
+def enable_wgrad_stream(on=True):
+    _WG["on"] = bool(on)
+
+
+def wgrad_stream(device):
+    key = (device.type, device.index)
+    st = _WG["streams"].get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _WG["streams"][key] = st
+    return st
+
+
+def _is_wgrad_out(t):
+    """heuristic-free marker: grad_like() tags the tensors it hands out"""
+    return getattr(t, "_cidnet_wgrad", False)
+
+
+def _in_arena(t):
+    base, n, flat_g, _ = _ARENA
+    gb = flat_g.data_ptr()
+    return gb <= t.data_ptr() < gb + 4 * n
+
+
+def _offload_wgrad(tensors, fn):
+    """tensors = (inputs..., outputs...) of fn; outputs are the trailing grad_like() results.  Falls back to
+    the caller's stream unless every weight-gradient output lives in the arena (otherwise autograd would
+    read it on the caller's stream before this stream has written it)."""
+    if not _WG["on"] or _ARENA is None or not all(_in_arena(t) for t in tensors if t.dim() >= 1 and _is_wgrad_out(t)):
+        fn()
+        return
+    main = torch.cuda.current_stream()
+    st = wgrad_stream(tensors[0].device)
+    st.wait_stream(main)
+    with torch.cuda.stream(st):
+        fn()
+    for t in tensors:
+        t.record_stream(st)
+
+
 def _po(t, off_floats=0):
     return _vp(t.data_ptr() + 4 * int(off_floats))
 
@@ -316,8 +362,9 @@ class CABResidualFn(torch.autograd.Function):
         # pointwise backward
         g_wq = grad_like(wq)
         g_wkv = grad_like(wkv)
-        pw_wgrad(dqkv0, 0, 3 * C * HW, xn, 0, C * HW, g_wq, 0, C, B, C, C, HW)
-        pw_wgrad(dqkv0, C * HW, 3 * C * HW, yn, 0, C * HW, g_wkv, 0, C, B, 2 * C, C, HW)
+        _offload_wgrad((dqkv0, xn, yn, g_wq, g_wkv), lambda: (
+            pw_wgrad(dqkv0, 0, 3 * C * HW, xn, 0, C * HW, g_wq, 0, C, B, C, C, HW),
+            pw_wgrad(dqkv0, C * HW, 3 * C * HW, yn, 0, C * HW, g_wkv, 0, C, B, 2 * C, C, HW)))
         dxn = dyn = None
         if ctx.needs_input_grad[1]:
             dxn = torch.empty_like(xn)
@@ -363,7 +410,7 @@ class IELFn(torch.autograd.Function):
         h = w_dw1.shape[0]
         go = _c(go)
         g_wout = grad_like(w_out)
-        pw_wgrad(go, 0, C * HW, gate, 0, h * HW, g_wout, 0, h, B, C, h, HW)
+        _offload_wgrad((go, gate, g_wout), lambda: pw_wgrad(go, 0, C * HW, gate, 0, h * HW, g_wout, 0, h, B, C, h, HW))
         dg = torch.empty_like(gate)
         pw_conv(go, 0, C * HW, w_out, 0, 0, 1, h, dg, 0, h * HW, B, h, C, HW)
         da = torch.empty_like(u)
@@ -377,7 +424,7 @@ class IELFn(torch.autograd.Function):
         dpin = da                                       # reuse
         dw3x3_bwd(pin, du, w_dw, None, 2 * h, dpin, g_dw, None, B, 2 * h, H, W)
         g_win = grad_like(w_in)
-        pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW)
+        _offload_wgrad((dpin, xn, g_win), lambda: pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW))
         dxn = None
         if ctx.needs_input_grad[0]:
             dxn = torch.empty_like(xn)
@@ -416,7 +463,7 @@ class DownFn(torch.autograd.Function):
         dt = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
         bilinear_bwd(dpre, dt, B, Co, H, W, H // 2, W // 2)
         gw = grad_like(w)
-        conv3x3_wgrad(dt, x, gw, B, Co, Ci, H, W)
+        _offload_wgrad((dt, x, gw), lambda: conv3x3_wgrad(dt, x, gw, B, Co, Ci, H, W))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -469,7 +516,7 @@ class UpFn(torch.autograd.Function):
         dt = torch.empty_like(t)
         pw_conv(dz, 0, Co * HWl, w_up, 0, 0, 1, 2 * Co, dt, 0, Co * HWl, B, Co, Co, HWl)
         gw = grad_like(w)
-        conv3x3_wgrad(dt, x, gw, B, Co, Ci, h, wd)
+        _offload_wgrad((dt, x, gw), lambda: conv3x3_wgrad(dt, x, gw, B, Co, Ci, h, wd))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -498,7 +545,7 @@ class RepConv3x3Fn(torch.autograd.Function):
         Co = w.shape[0]
         go = _c(go)
         gw = grad_like(w)
-        conv3x3_wgrad(go, x, gw, B, Co, Ci, H, W, replicate=True)
+        _offload_wgrad((go, x, gw), lambda: conv3x3_wgrad(go, x, gw, B, Co, Ci, H, W, replicate=True))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -620,8 +667,12 @@ def grad_like(w):
         base, n, flat_g, excl = _ARENA
         off = (w.data_ptr() - base) // 4
         if 0 <= off < n and w.data_ptr() not in excl and w.is_contiguous():
-            return flat_g[off:off + w.numel()].view(w.shape)
-    return torch.empty_like(w)
+            g = flat_g[off:off + w.numel()].view(w.shape)
+            g._cidnet_wgrad = True
+            return g
+    g = torch.empty_like(w)
+    g._cidnet_wgrad = True
+    return g
 
 
 # --------------------------------------------------------------------------------------------
