@@ -29,13 +29,14 @@ class CIDNet_TNSM(_BaseCIDNet):
             self.noise_fusion = nn.Sequential(nn.Conv2d(12, 3, kernel_size=3, padding=1, bias=False), nn.Sigmoid())
 
     def _stage(self, n, i_in, hv_in, maps):
-        """I_LCAn / HV_LCAn, then (use_tnsm) I_TNSMn / HV_TNSMn on the LCA outputs (CIDNet_TNSM.py:124-136 etc.)"""
-        i_l = getattr(self, f"I_LCA{n}")(i_in, hv_in)
-        hv_l = getattr(self, f"HV_LCA{n}")(hv_in, i_in)
+        """I_LCAn / HV_LCAn, then (use_tnsm) I_TNSMn / HV_TNSMn on the LCA outputs (CIDNet_TNSM.py:124-136 etc.);
+        the I and HV halves of each pair run on the two branch streams"""
+        i_l, hv_l = self._par(lambda: getattr(self, f"I_LCA{n}")(i_in, hv_in),
+                              lambda: getattr(self, f"HV_LCA{n}")(hv_in, i_in), (i_in, hv_in))
         if not self.use_tnsm:
             return i_l, hv_l
-        i_t, i_n = getattr(self, f"I_TNSM{n}")(i_l, hv_l)
-        hv_t, hv_n = getattr(self, f"HV_TNSM{n}")(hv_l, i_l)
+        (i_t, i_n), (hv_t, hv_n) = self._par(lambda: getattr(self, f"I_TNSM{n}")(i_l, hv_l),
+                                             lambda: getattr(self, f"HV_TNSM{n}")(hv_l, i_l), (i_l, hv_l))
         maps.extend([i_n, hv_n])
         return i_t, hv_t
 
