@@ -22,6 +22,12 @@ constexpr float kTwoPi = 6.28318548202514648f;   // float(2.0 * pi)
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;
 
+// base^k for base in [1e-8, 1+1e-8] through the hardware log2 / exp2 (v_log_f32, v_exp_f32: <= 1 ulp each).
+// |k log2(base)| <= 27 k, so the absolute error of the exponent is <= 3e-6 * k and the relative error of the
+// result <= 2e-6 * k (4e-7 at k = 0.2) -- an order of magnitude cheaper than the library powf, which was the
+// single largest VALU cost of these HBM-bound kernels.
+__device__ __forceinline__ float pow_fast(float base, float k) { return __builtin_amdgcn_exp2f(k * __builtin_amdgcn_logf(base)); }
+
 __device__ __forceinline__ void stage_trig(float2* T) {
   for (int i = threadIdx.x; i <= CIDNET_TRIG_N; i += blockDim.x) T[i] = g_trig_table[i];
   __syncthreads();
@@ -74,7 +80,7 @@ __device__ __forceinline__ HvitPx hvit_px(float r, float g, float b, float k, co
   const float xs = (o.value * 0.5f) * kPi;
   sincos_tab(T, xs, o.sn, o.csn);
   o.base = o.sn + kEps;
-  o.cs = powf(o.base, k);
+  o.cs = pow_fast(o.base, k);
   sincos_tab(T, kTwoPi * o.hue, o.cv, o.ch);
   return o;
 }
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void hvit_bwd_kernel(const float* __restr
       const float g_cs = o.sat * A;
       const float g_sat = o.cs * A;
       const float g_hue6 = (o.cs * o.sat) * (gv[e] * o.ch - gh[e] * o.cv) * (kTwoPi / 6.0f);
-      if (e < n) gk_acc += g_cs * o.cs * logf(o.base);
+      if (e < n) gk_acc += g_cs * o.cs * (0.693147180559945f * __builtin_amdgcn_logf(o.base));
       // cs = base^k, base = sin(value*pi/2) + eps
       float g_value = gi[e] + g_cs * k * (o.cs / o.base) * o.csn * (0.5f * kPi);
       float g_delta = 0.f;
@@ -217,7 +223,7 @@ __device__ __forceinline__ PhvitPx phvit_px(float H0, float V0, float I0, float 
   o.I1 = fminf(fmaxf(I0, 0.f), 1.f);
   sincos_tab(T, (o.I1 * 0.5f) * kPi, o.sn, o.csn);
   o.base = o.sn + kEps;
-  o.cs = (k == 0.f) ? 1.0f : powf(o.base, k);
+  o.cs = (k == 0.f) ? 1.0f : pow_fast(o.base, k);
   o.den = o.cs + kEps;
   o.H2 = o.H1 / o.den;
   o.V2 = o.V1 / o.den;
