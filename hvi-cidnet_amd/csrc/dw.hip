@@ -275,6 +275,155 @@ __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward of the IEL gate and of dwconv1 / dwconv2 (net/LCA.py:62-64):
+//   forward:  a_i = dw_i(u_i), t_i = tanh(a_i), s_i = t_i + u_i, g = s1 * s2        (i = 1, 2)
+//   backward: ds_1 = dg * s2, da_1 = ds_1 * (1 - t1^2)   (and symmetrically for 2)
+//             du_i = ds_i + dw_i^T(da_i),   gw_i[tap] = sum da_i[p] * u_i[p + tap]
+// The unfused path wrote da, ds (4h channels) and read them back (plus u again) in a second kernel; here a
+// lane recomputes da on its strip plus a one-pixel halo from an 8-wide register window of u, so the only
+// HBM traffic is: read dg (h), read u (2h), write du (2h).  One lane = one channel pair, 4 px x kRows rows.
+struct Row8 {
+  float v[8];
+};
+// pixels x0-2 .. x0+5 of row yy of a plane (zero outside the image)
+__device__ __forceinline__ Row8 load_row8(const float* __restrict__ plane, int yy, int x0, int H, int W) {
+  Row8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
+  if (yy < 0 || yy >= H) return r;
+  const float* row = plane + (long)yy * W;
+  if (x0 >= 2 && x0 + 6 <= W) {
+    const f32x4 a = load4u(row + x0 - 2), b = load4u(row + x0 + 2);
+    r.v[0] = a[0]; r.v[1] = a[1]; r.v[2] = a[2]; r.v[3] = a[3];
+    r.v[4] = b[0]; r.v[5] = b[1]; r.v[6] = b[2]; r.v[7] = b[3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int x = x0 - 2 + i;
+      if (x >= 0 && x < W) r.v[i] = row[x];
+    }
+  }
+  return r;
+}
+
+struct GateRow {      // da, ds of one row on the 6-wide window x0-1 .. x0+4, for both channels of the pair
+  float da1[6], da2[6], ds1[6], ds2[6];
+};
+
+__device__ __forceinline__ GateRow gate_bwd_row(const Row8& a0, const Row8& a1, const Row8& a2, const Row8& b0, const Row8& b1,
+                                                const Row8& b2, const Row6& dg, const float* wa, const float* wb) {
+  GateRow o;
+#pragma unroll
+  for (int jx = 0; jx < 6; ++jx) {
+    const float c1 = wa[0] * a0.v[jx] + wa[1] * a0.v[jx + 1] + wa[2] * a0.v[jx + 2] + wa[3] * a1.v[jx] + wa[4] * a1.v[jx + 1] +
+                     wa[5] * a1.v[jx + 2] + wa[6] * a2.v[jx] + wa[7] * a2.v[jx + 1] + wa[8] * a2.v[jx + 2];
+    const float c2 = wb[0] * b0.v[jx] + wb[1] * b0.v[jx + 1] + wb[2] * b0.v[jx + 2] + wb[3] * b1.v[jx] + wb[4] * b1.v[jx + 1] +
+                     wb[5] * b1.v[jx + 2] + wb[6] * b2.v[jx] + wb[7] * b2.v[jx + 1] + wb[8] * b2.v[jx + 2];
+    const float t1 = tanhf(c1), t2 = tanhf(c2);
+    const float s1 = t1 + a1.v[jx + 1], s2 = t2 + b1.v[jx + 1];
+    const float g = dg.v[jx];
+    o.ds1[jx] = g * s2; o.ds2[jx] = g * s1;
+    o.da1[jx] = o.ds1[jx] * (1.f - t1 * t1); o.da2[jx] = o.ds2[jx] * (1.f - t2 * t2);
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* __restrict__ u, const float* __restrict__ w1,
+                                                                   const float* __restrict__ w2, const float* __restrict__ dg,
+                                                                   float* __restrict__ du, float* __restrict__ part, int h, int H,
+                                                                   int W, int nchunk) {
+  __shared__ float red[kThreads / 64];
+  const int nxg = (((W + 3) >> 2) + 15) >> 4;
+  const int nstrips = (H + kRows - 1) / kRows;
+  const long bc = blockIdx.y;                    // b * h + c
+  const int c = (int)(bc % h);
+  const long b = bc / h;
+  const long HW = (long)H * W;
+  const float* p1 = u + (b * 2 * h + c) * HW;
+  const float* p2 = u + (b * 2 * h + h + c) * HW;
+  const float* gp = dg + bc * HW;
+  float* o1 = du + (b * 2 * h + c) * HW;
+  float* o2 = du + (b * 2 * h + h + c) * HW;
+  float wa[9], wb[9], fa[9], fb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wa[t] = w1[(long)c * 9 + t]; wb[t] = w2[(long)c * 9 + t];
+    fa[t] = w1[(long)c * 9 + 8 - t]; fb[t] = w2[(long)c * 9 + 8 - t];
+  }
+  float acc1[9], acc2[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc1[t] = 0.f; acc2[t] = 0.f; }
+
+  for (int sub = 0; sub < kSub; ++sub) {
+    const long idx = ((long)blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
+    const int xl = (int)(idx & 15);
+    const long rest = idx >> 4;
+    const int xg = (int)(rest % nxg), strip = (int)(rest / nxg);
+    const int x0 = (xg * 16 + xl) * 4, y0 = strip * kRows;
+    if (!(strip < nstrips && x0 < W)) continue;
+    const int yend = min(y0 + kRows, H);
+    // u windows hold rows r-1, r, r+1 while row r of (da, ds) is being formed
+    Row8 a0, a1 = load_row8(p1, y0 - 2, x0, H, W), a2 = load_row8(p1, y0 - 1, x0, H, W);
+    Row8 b0, b1 = load_row8(p2, y0 - 2, x0, H, W), b2 = load_row8(p2, y0 - 1, x0, H, W);
+    GateRow gm, gc;                              // rows r-2 and r-1
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { gm.da1[i] = gm.da2[i] = gm.ds1[i] = gm.ds2[i] = 0.f; gc = gm; }
+    for (int r = y0 - 1; r <= yend; ++r) {
+      a0 = a1; a1 = a2; a2 = load_row8(p1, r + 1, x0, H, W);
+      b0 = b1; b1 = b2; b2 = load_row8(p2, r + 1, x0, H, W);
+      const Row6 dgr = load_row6(gp, r, x0, H, W);            // zero outside the image => da = ds = 0 there
+      const GateRow gn = gate_bwd_row(a0, a1, a2, b0, b1, b2, dgr, wa, wb);
+      if (r >= y0 && r < yend) {                               // weight gradients: this lane's own pixels of row r
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d1 = gn.da1[e + 1], d2 = gn.da2[e + 1];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            acc1[dx] += d1 * a0.v[e + dx + 1]; acc1[3 + dx] += d1 * a1.v[e + dx + 1]; acc1[6 + dx] += d1 * a2.v[e + dx + 1];
+            acc2[dx] += d2 * b0.v[e + dx + 1]; acc2[3 + dx] += d2 * b1.v[e + dx + 1]; acc2[6 + dx] += d2 * b2.v[e + dx + 1];
+          }
+        }
+      }
+      const int q = r - 1;                                     // du row q needs da rows q-1 (gm), q (gc), q+1 (gn)
+      if (q >= y0 && q < yend) {
+        f32x4 d1, d2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d1[e] = gc.ds1[e + 1] + fa[0] * gm.da1[e] + fa[1] * gm.da1[e + 1] + fa[2] * gm.da1[e + 2] + fa[3] * gc.da1[e] +
+                  fa[4] * gc.da1[e + 1] + fa[5] * gc.da1[e + 2] + fa[6] * gn.da1[e] + fa[7] * gn.da1[e + 1] + fa[8] * gn.da1[e + 2];
+          d2[e] = gc.ds2[e + 1] + fb[0] * gm.da2[e] + fb[1] * gm.da2[e + 1] + fb[2] * gm.da2[e + 2] + fb[3] * gc.da2[e] +
+                  fb[4] * gc.da2[e + 1] + fb[5] * gc.da2[e + 2] + fb[6] * gn.da2[e] + fb[7] * gn.da2[e + 1] + fb[8] * gn.da2[e + 2];
+        }
+        store_row4(o1, q, x0, W, d1);
+        store_row4(o2, q, x0, W, d2);
+      }
+      gm = gc; gc = gn;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float s1 = block_sum(acc1[t], red);
+    const float s2 = block_sum(acc2[t], red);
+    if (threadIdx.x == 0) {
+      part[((bc * nchunk + blockIdx.x) * 2) * 9 + t] = s1;
+      part[((bc * nchunk + blockIdx.x) * 2 + 1) * 9 + t] = s2;
+    }
+  }
+}
+
+// gw1[c][t], gw2[c][t] = sum_b sum_chunk part[((b*h + c)*nchunk + chunk)*2 + {0,1}][t]
+__global__ void gate_wgrad_reduce_kernel(const float* __restrict__ part, int B, int h, int nchunk, float* __restrict__ gw1,
+                                         float* __restrict__ gw2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h * 18) return;
+  const int c = i / 18, r = i - c * 18, which = r / 9, t = r - which * 9;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < nchunk; ++k) s += part[((((long)b * h + c) * nchunk + k) * 2 + which) * 9 + t];
+  (which ? gw2 : gw1)[(long)c * 9 + t] = s;
+}
+
 // gw[c][t] (+)= sum_b sum_chunk part[((b*C + c)*nchunk + chunk)*9 + t]
 __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int B, int C, int nchunk, float* __restrict__ gw1,
                                        float* __restrict__ gw2, int csplit) {
@@ -361,6 +510,26 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, C,
                      nchunk, gw1, gw2, csplit);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+long cidnet_iel_gate_dw_bwd_ws_floats(int B, int h, int H, int W) {
+  return (long)B * h * ((wgrad_chunks(H, W) + kSub - 1) / kSub) * 18;
+}
+
+/* du = d(loss)/d(u) of the gate INCLUDING the backward of dwconv1/dwconv2, and their weight gradients, in one
+ * pass: reads dg (B,h,H,W) and u (B,2h,H,W), writes du (B,2h,H,W), gw1/gw2 (h,1,3,3). */
+int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* du, float* gw1, float* gw2,
+                           float* ws, long ws_floats, int B, int h, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(u && w1 && w2 && dg && du && gw1 && gw2 && ws && B > 0 && h > 0 && H > 0 && W > 0);
+  if (ws_floats < cidnet_iel_gate_dw_bwd_ws_floats(B, h, H, W)) return CIDNET_ERR_WS;
+  const int nchunk = (wgrad_chunks(H, W) + kSub - 1) / kSub;
+  hipLaunchKernelGGL(iel_gate_dw_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * h)), dim3(kThreads), 0, (hipStream_t)stream, u,
+                     w1, w2, dg, du, ws, h, H, W, nchunk);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((h * 18 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, h,
+                     nchunk, gw1, gw2);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

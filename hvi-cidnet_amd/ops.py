@@ -413,15 +413,15 @@ class IELFn(torch.autograd.Function):
         _offload_wgrad((go, gate, g_wout), lambda: pw_wgrad(go, 0, C * HW, gate, 0, h * HW, g_wout, 0, h, B, C, h, HW))
         dg = torch.empty_like(gate)
         pw_conv(go, 0, C * HW, w_out, 0, 0, 1, h, dg, 0, h * HW, B, h, C, HW)
-        da = torch.empty_like(u)
-        ds = torch.empty_like(u)
-        lib().call("cidnet_iel_gate_bwd", _p(u), _p(w_dw1), _p(w_dw2), _p(dg), _p(da), _p(ds), B, h, H, W, _stream())
         g_dw1 = grad_like(w_dw1)
         g_dw2 = grad_like(w_dw2)
-        du = ds                                         # du = ds + dw^T(da), written in place over ds
-        dw3x3_bwd(u, da, w_dw1, w_dw2, h, du, g_dw1, g_dw2, B, 2 * h, H, W, addend=ds)
+        du = torch.empty_like(u)                        # gate backward + dwconv1/2 backward in one pass
+        n = _raw("cidnet_iel_gate_dw_bwd_ws_floats", B, h, H, W)
+        ws = _ws(n, u.device)
+        lib().call("cidnet_iel_gate_dw_bwd", _p(u), _p(w_dw1), _p(w_dw2), _p(dg), _p(du), _p(g_dw1), _p(g_dw2), _p(ws), ws.numel(),
+                   B, h, H, W, _stream())
         g_dw = grad_like(w_dw)
-        dpin = da                                       # reuse
+        dpin = torch.empty_like(u)
         dw3x3_bwd(pin, du, w_dw, None, 2 * h, dpin, g_dw, None, B, 2 * h, H, W)
         g_win = grad_like(w_in)
         _offload_wgrad((dpin, xn, g_win), lambda: pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW))

@@ -112,6 +112,12 @@ int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float*
 /* da = d(dw1/2 output), ds = d(s1/s2) both (B,2h,H,W); du = ds + dw3x3(da, flipped) by the caller. */
 int cidnet_iel_gate_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* da,
                         float* ds, int B, int h, int H, int W, void* stream);
+/* fused: du = ds + dw^T(da) with da, ds recomputed on the fly, plus the dwconv1/dwconv2 weight gradients;
+ * HBM traffic: read dg (h) + u (2h), write du (2h) -- the unfused pair moved 15h channel passes */
+long cidnet_iel_gate_dw_bwd_ws_floats(int B, int h, int H, int W);
+int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* du,
+                           float* gw1, float* gw2, float* ws, long ws_floats, int B, int h, int H, int W,
+                           void* stream);
 
 /* ---- K9/K10/K11: dense 3x3 convolution, pad 1, fp32 MFMA implicit GEMM -------------------------
  * (net/transformer_utils.py:39,58 zero pad; net/CIDNet.py:21-24,32-35,39-42,50-53 replicate pad)

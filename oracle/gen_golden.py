@@ -38,6 +38,58 @@ torch.manual_seed(0)
 torch.set_num_threads(8)
 
 
+class KinkMargin:
+    """Smallest distance of any non-smooth point's argument from its kink over one forward of a reference
+    model: PReLU / ReLU / LeakyReLU inputs from 0 and the runner-up gap of a channel max (SpatialAttention,
+    net/CIDNet_MSSA.py:22).  A gradient fixture whose margin is below the forward tolerance tests on which
+    side of a kink fp32 rounding happens to fall, not parity: one flipped PReLU pixel moves whole gradient
+    tensors by percents.  Whole-model fixtures are therefore generated from the first input seed whose
+    margin is >= MIN_MARGIN, and the margin is stored next to them."""
+    MIN_MARGIN = 4e-6
+
+    def __init__(self, model):
+        self.margin, self.hooks = float("inf"), []
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.PReLU, torch.nn.ReLU, torch.nn.LeakyReLU)):
+                self.hooks.append(mod.register_forward_pre_hook(self._act))
+            elif type(mod).__name__ == "SpatialAttention":
+                self.hooks.append(mod.register_forward_pre_hook(self._chmax))
+
+    def _act(self, mod, inp):
+        if inp[0].dim() == 4 and inp[0].shape[-1] > 1:      # feature maps, not the pooled TNSM vectors
+            self.margin = min(self.margin, inp[0].detach().abs().min().item())
+
+    def _chmax(self, mod, inp):
+        top = inp[0].detach().topk(2, dim=1).values
+        self.margin = min(self.margin, (top[:, 0] - top[:, 1]).min().item())
+
+    def loss(self, y, gt):                                   # the L1 loss's own kink, |y - gt| = 0
+        self.margin = min(self.margin, (y.detach() - gt).abs().min().item())
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+        return self.margin
+
+
+def pick_input_seed(make_model, shape, run, first=51, tries=40):
+    """the input seed among first, first+100, ... whose forward stays farthest from every kink"""
+    best = (-1.0, None)
+    for t in range(tries):
+        seed = first + 100 * t
+        m = make_model()
+        x, gt = O.synthetic_batch(seed, shape), O.synthetic_batch(seed + 1, shape)
+        km = KinkMargin(m)
+        with torch.no_grad():
+            km.loss(run(m, x), gt)
+        best = max(best, (km.close(), seed))
+        if best[0] >= KinkMargin.MIN_MARGIN:
+            break
+    print(f"  input seed {best[1]}: kink margin {best[0]:.2e}")
+    assert best[0] >= 1e-6, "no input seed with a usable kink margin"
+    return best[1], best[0]
+
+
 def adversarial_pixels() -> torch.Tensor:
     """(1,3,1,N) image of hand-picked pixels: gray, black, white, primaries, all tie patterns."""
     px = [
@@ -333,11 +385,17 @@ def gen_mssa():
                sa_gw=sa.conv1.weight.grad.numpy())
     chans = (12, 12, 24, 48)
     p = O.make_params(5, channels=chans, variant="mssa")
-    m = RefMSSA(channels=list(chans))
-    load_into(m, p)
+
+    def make():
+        mm = RefMSSA(channels=list(chans))
+        load_into(mm, p)
+        return mm
+    seed, margin = pick_input_seed(make, (2, 3, 32, 48), lambda mm, xx: mm(xx))
+    m = make()
     assert len(m.state_dict()) == 197
-    x = O.synthetic_batch(51, (2, 3, 32, 48))
-    gt = O.synthetic_batch(52, (2, 3, 32, 48))
+    x = O.synthetic_batch(seed, (2, 3, 32, 48))
+    gt = O.synthetic_batch(seed + 1, (2, 3, 32, 48))
+    out["model_kink_margin"] = np.float64(margin)
     yr = m(x)
     (yr - gt).abs().mean().backward()
     po = O.params_to(p, requires_grad=True)

@@ -150,3 +150,24 @@ def test_bilinear_bwd_and_down(dev, B, C, Hi, Wi, Ho, Wo):
         lib().call("cidnet_down_prelu_fwd", ops._p(xd), ops._p(sd), ops._p(pre), ops._p(out), B, C, Hi, Wi, ops._stream())
         close(pre, yr, what="down")
         close(out, F.prelu(yr, slope), what="down+prelu")
+
+
+@pytest.mark.parametrize("B,h,H,W", [(2, 5, 9, 13), (1, 31, 16, 24), (2, 127, 4, 6), (1, 7, 3, 3), (1, 63, 8, 12), (1, 95, 40, 300)])
+def test_iel_gate_dw_bwd_fused_equals_unfused(dev, B, h, H, W):
+    """fused gate + dwconv1/2 backward == gate_bwd followed by the depthwise backward"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    u, dg = rnd(51, (B, 2 * h, H, W), 1.5).to(dev), rnd(52, (B, h, H, W)).to(dev)
+    w1, w2 = rnd(53, (h, 1, 3, 3), 0.5).to(dev), rnd(54, (h, 1, 3, 3), 0.5).to(dev)
+    da, ds = torch.empty_like(u), torch.empty_like(u)
+    lib().call("cidnet_iel_gate_bwd", ops._p(u), ops._p(w1), ops._p(w2), ops._p(dg), ops._p(da), ops._p(ds), B, h, H, W, ops._stream())
+    du_ref, g1_ref, g2_ref = torch.empty_like(u), torch.empty_like(w1), torch.empty_like(w2)
+    ops.dw3x3_bwd(u, da, w1, w2, h, du_ref, g1_ref, g2_ref, B, 2 * h, H, W, addend=ds)
+    du, g1, g2 = torch.empty_like(u), torch.empty_like(w1), torch.empty_like(w2)
+    n = lib().raw("cidnet_iel_gate_dw_bwd_ws_floats")(B, h, H, W)
+    ws = torch.empty(n, device=dev)
+    lib().call("cidnet_iel_gate_dw_bwd", ops._p(u), ops._p(w1), ops._p(w2), ops._p(dg), ops._p(du), ops._p(g1), ops._p(g2), ops._p(ws),
+               n, B, h, H, W, ops._stream())
+    close(du, du_ref, what="du")
+    close(g1, g1_ref, what="gw1")
+    close(g2, g2_ref, what="gw2")
