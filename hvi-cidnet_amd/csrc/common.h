@@ -46,6 +46,16 @@ __device__ __forceinline__ void store4u(float* p, f32x4 v) {
   *reinterpret_cast<f4u*>(p) = s;
 }
 
+// tanh on the hardware exp2 / rcp units (about 10 VALU ops instead of the library's ~50): 1 - 2/(e^{2x} + 1) away
+// from zero, the odd Taylor polynomial through x^7 for |x| < 0.2 where that form cancels.  Absolute error < 1.5e-7.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);          // e^{2x}; inf / 0 at the extremes
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float x2 = x * x;
+  const float small = x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * -0.053968254f)));
+  return fabsf(x) < 0.2f ? small : big;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -2,17 +2,19 @@
 // taps) / weight-gradient, and the IEL gate  g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2)
 // forward and backward (reference: net/LCA.py:14,16,53-55,62-65).
 //
-// All kernels share one tiling: a lane owns a 4-pixel-wide, kRows-tall column strip of one (b,c)
+// All kernels share one tiling: a lane owns a 4-pixel-wide, `rows`-tall column strip of one (b,c)
 // plane and slides a 3-row register window down it, so each input row is fetched once per strip
-// (+2 halo rows per 8) as one 16 B load plus two neighbour scalars that hit L1.  16 adjacent lanes
-// cover 64 contiguous pixels of a row.  HBM-bound by construction (2 FLOP per byte).
+// (+ halo rows per strip) as one 16 B load plus two neighbour scalars that hit L1.  Consecutive lanes
+// cover consecutive 16 B pieces of a row (dense: ceil(W/4) lanes per row, no padding to a power of
+// two), then the next strip.  The strip height is picked per launch (pick_tiling): as tall as the
+// plane count allows, because every strip re-reads its halo rows.  HBM-bound by construction.
 #include "common.h"
 
 namespace cidnet {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRows = 8;
+constexpr int kMinRows = 8, kMaxRows = 24;
 constexpr int kSub = 4;     // 256-item groups a fused-backward block walks before reducing
 
 struct Row6 {
@@ -65,28 +67,54 @@ struct Item {
   bool live;
 };
 
-// flattened work decomposition: ((bc * nstrips + strip) * nxg + xg) * 16 + xl
-__device__ __forceinline__ Item decode_item(long planes, int H, int W) {
-  const int nxg = (((W + 3) >> 2) + 15) >> 4;
-  const int nstrips = (H + kRows - 1) / kRows;
+struct Tiling {
+  int nx4;       // lanes per row = ceil(W / 4)
+  int rows;      // strip height
+  int nstrips;   // ceil(H / rows)
+};
+
+// flattened work decomposition: (bc * nstrips + strip) * nx4 + xl
+__device__ __forceinline__ Item decode_item(long planes, Tiling tl, int W) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   Item it;
-  const long xl = idx & 15;
-  long rest = idx >> 4;
-  const long xg = rest % nxg; rest /= nxg;
-  const long strip = rest % nstrips;
-  it.bc = rest / nstrips;
-  it.y0 = (int)strip * kRows;
-  it.x0 = (int)(xg * 16 + xl) * 4;
-  it.live = it.bc < planes && it.x0 < W;
+  const long xl = idx % tl.nx4;
+  const long rest = idx / tl.nx4;
+  const long strip = rest % tl.nstrips;
+  it.bc = rest / tl.nstrips;
+  it.y0 = (int)strip * tl.rows;
+  it.x0 = (int)xl * 4;
+  it.live = it.bc < planes;
   return it;
 }
 
-inline long n_items(long planes, int H, int W) {
-  const long nxg = (((W + 3) >> 2) + 15) >> 4;
-  const long nstrips = (H + kRows - 1) / kRows;
-  return planes * nstrips * nxg * 16;
+// Strip height.  A strip costs rows + halo row passes, so taller strips re-read less; but these kernels are
+// latency-bound per lane (one row per iteration), so the launch must keep several rounds of resident waves
+// (`min_lanes`), and in the block-per-plane kernels a plane's items are rounded up to whole waves.  Cost model:
+// lane-iterations = lanes (rounded to waves if per_plane) x (rows + halo); heights above kMinRows are only
+// taken while the launch keeps min_lanes lanes.
+int g_dw_force_rows = 0;     // timing studies only (cidnet_debug_dw_rows)
+
+inline Tiling pick_tiling(long planes, int H, int W, int halo, long min_lanes, bool per_plane) {
+  const int nx4 = (W + 3) >> 2;
+  if (g_dw_force_rows > 0) {
+    const int r = g_dw_force_rows < H ? g_dw_force_rows : H;
+    return Tiling{nx4, r, (H + r - 1) / r};
+  }
+  Tiling best{nx4, 0, 0};
+  long best_cost = -1;
+  const int lo = H < 4 ? H : 4, hi = H < kMaxRows ? H : kMaxRows;
+  for (int r = lo; r <= hi; ++r) {
+    const int ns = (H + r - 1) / r;
+    const long items = (long)ns * nx4;
+    if (r > kMinRows && planes * items < min_lanes) break;
+    const long lanes = per_plane ? ((items + 63) / 64) * 64 : items;
+    const long cost = lanes * (r + halo);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best.rows = r; best.nstrips = ns; }
+  }
+  return best;
 }
+
+inline long n_items(long planes, Tiling tl) { return planes * tl.nstrips * tl.nx4; }
 
 __device__ __forceinline__ void load_w9(const float* w1, const float* w2, int csplit, int c, bool flip, float* w) {
   const float* src = (c < csplit) ? w1 + (long)c * 9 : w2 + (long)(c - csplit) * 9;
@@ -98,8 +126,8 @@ __device__ __forceinline__ void load_w9(const float* w1, const float* w2, int cs
 __global__ __launch_bounds__(kThreads) void dw3x3_kernel(const float* __restrict__ in, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, int csplit,
                                                          const float* __restrict__ addend, float* __restrict__ out, int flip,
-                                                         int B, int C, int H, int W) {
-  const Item it = decode_item((long)B * C, H, W);
+                                                         int B, int C, int H, int W, Tiling tl) {
+  const Item it = decode_item((long)B * C, tl, W);
   if (!it.live) return;
   float w[9];
   load_w9(w1, w2, csplit, (int)(it.bc % C), flip != 0, w);
@@ -109,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void dw3x3_kernel(const float* __restrict
   const float* ap = addend ? addend + it.bc * HW : nullptr;
   Row6 r0 = load_row6(ip, it.y0 - 1, it.x0, H, W);
   Row6 r1 = load_row6(ip, it.y0, it.x0, H, W);
-  const int yend = min(it.y0 + kRows, H);
+  const int yend = min(it.y0 + tl.rows, H);
   for (int y = it.y0; y < yend; ++y) {
     const Row6 r2 = load_row6(ip, y + 1, it.x0, H, W);
     f32x4 o = stencil(r0, r1, r2, w);
@@ -128,8 +156,8 @@ template <int MODE>
 __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restrict__ u, const float* __restrict__ w1,
                                                             const float* __restrict__ w2, const float* __restrict__ dg,
                                                             float* __restrict__ g, float* __restrict__ da,
-                                                            float* __restrict__ ds, int B, int h, int H, int W) {
-  const Item it = decode_item((long)B * h, H, W);
+                                                            float* __restrict__ ds, int B, int h, int H, int W, Tiling tl) {
+  const Item it = decode_item((long)B * h, tl, W);
   if (!it.live) return;
   const int c = (int)(it.bc % h);
   const long b = it.bc / h;
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
   const float* p2 = u + (b * 2 * h + h + c) * HW;
   Row6 a0 = load_row6(p1, it.y0 - 1, it.x0, H, W), a1 = load_row6(p1, it.y0, it.x0, H, W);
   Row6 b0 = load_row6(p2, it.y0 - 1, it.x0, H, W), b1 = load_row6(p2, it.y0, it.x0, H, W);
-  const int yend = min(it.y0 + kRows, H);
+  const int yend = min(it.y0 + tl.rows, H);
   for (int y = it.y0; y < yend; ++y) {
     const Row6 a2 = load_row6(p1, y + 1, it.x0, H, W);
     const Row6 b2 = load_row6(p2, y + 1, it.x0, H, W);
@@ -149,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
     f32x4 t1, t2, s1, s2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      t1[e] = tanhf(c1[e]); t2[e] = tanhf(c2[e]);
+      t1[e] = tanh_fast(c1[e]); t2[e] = tanh_fast(c2[e]);
       s1[e] = t1[e] + a1.v[1 + e]; s2[e] = t2[e] + b1.v[1 + e];
     }
     if (MODE == 0) {
@@ -173,17 +201,13 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
 
 // gw[c][t] partial over one block of strips of plane (b,c):  sum gout[y][x] * in[y+dy-1][x+dx-1]
 __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
-                                                               float* __restrict__ part, int H, int W, int nchunk) {
+                                                               float* __restrict__ part, int H, int W, int nchunk, Tiling tl) {
   __shared__ float red[kThreads / 64];
-  const int nxg = (((W + 3) >> 2) + 15) >> 4;
-  const int nstrips = (H + kRows - 1) / kRows;
   const long bc = blockIdx.y;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // item inside the plane
-  const int xl = (int)(idx & 15);
-  const long rest = idx >> 4;
-  const int xg = (int)(rest % nxg), strip = (int)(rest / nxg);
-  const int x0 = (xg * 16 + xl) * 4, y0 = strip * kRows;
-  const bool live = strip < nstrips && x0 < W;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // item inside the plane
+  const int strip = idx / tl.nx4;
+  const int x0 = (idx - strip * tl.nx4) * 4, y0 = strip * tl.rows;
+  const bool live = strip < tl.nstrips;
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __re
     const float* ip = in + bc * HW;
     const float* gp = gout + bc * HW;
     Row6 r0 = load_row6(ip, y0 - 1, x0, H, W), r1 = load_row6(ip, y0, x0, H, W);
-    const int yend = min(y0 + kRows, H);
+    const int yend = min(y0 + tl.rows, H);
     for (int y = y0; y < yend; ++y) {
       const Row6 r2 = load_row6(ip, y + 1, x0, H, W);
       const Row6 gr = load_row6(gp, y, x0, H, W);
@@ -221,10 +245,8 @@ __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __re
 __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                              const float* __restrict__ w1, const float* __restrict__ w2, int csplit,
                                                              const float* __restrict__ addend, float* __restrict__ gin,
-                                                             float* __restrict__ part, int C, int H, int W, int nchunk) {
+                                                             float* __restrict__ part, int C, int H, int W, int nchunk, Tiling tl) {
   __shared__ float red[kThreads / 64];
-  const int nxg = (((W + 3) >> 2) + 15) >> 4;
-  const int nstrips = (H + kRows - 1) / kRows;
   const long bc = blockIdx.y;
   const long HW = (long)H * W;
   const float* ip = in + bc * HW;
@@ -237,17 +259,15 @@ __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __rest
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
   // a block walks kSub consecutive 256-item groups of the plane so the nine block reductions below
-  // are paid once per 4 * 8192 pixels
+  // are paid once per kSub groups
   for (int sub = 0; sub < kSub; ++sub) {
-    const long idx = ((long)blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
-    const int xl = (int)(idx & 15);
-    const long rest = idx >> 4;
-    const int xg = (int)(rest % nxg), strip = (int)(rest / nxg);
-    const int x0 = (xg * 16 + xl) * 4, y0 = strip * kRows;
-    if (!(strip < nstrips && x0 < W)) continue;
+    const int idx = (blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
+    const int strip = idx / tl.nx4;
+    const int x0 = (idx - strip * tl.nx4) * 4, y0 = strip * tl.rows;
+    if (strip >= tl.nstrips) continue;
     Row6 i0 = load_row6(ip, y0 - 1, x0, H, W), i1 = load_row6(ip, y0, x0, H, W);
     Row6 g0 = load_row6(gp, y0 - 1, x0, H, W), g1 = load_row6(gp, y0, x0, H, W);
-    const int yend = min(y0 + kRows, H);
+    const int yend = min(y0 + tl.rows, H);
     for (int y = y0; y < yend; ++y) {
       const Row6 i2 = load_row6(ip, y + 1, x0, H, W);
       const Row6 g2 = load_row6(gp, y + 1, x0, H, W);
@@ -282,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __rest
 //             du_i = ds_i + dw_i^T(da_i),   gw_i[tap] = sum da_i[p] * u_i[p + tap]
 // The unfused path wrote da, ds (4h channels) and read them back (plus u again) in a second kernel; here a
 // lane recomputes da on its strip plus a one-pixel halo from an 8-wide register window of u, so the only
-// HBM traffic is: read dg (h), read u (2h), write du (2h).  One lane = one channel pair, 4 px x kRows rows.
+// HBM traffic is: read dg (h), read u (2h), write du (2h).  One lane = one channel pair, 4 px x `rows` rows.
 struct Row8 {
   float v[8];
 };
@@ -320,7 +340,7 @@ __device__ __forceinline__ GateRow gate_bwd_row(const Row8& a0, const Row8& a1, 
                      wa[5] * a1.v[jx + 2] + wa[6] * a2.v[jx] + wa[7] * a2.v[jx + 1] + wa[8] * a2.v[jx + 2];
     const float c2 = wb[0] * b0.v[jx] + wb[1] * b0.v[jx + 1] + wb[2] * b0.v[jx + 2] + wb[3] * b1.v[jx] + wb[4] * b1.v[jx + 1] +
                      wb[5] * b1.v[jx + 2] + wb[6] * b2.v[jx] + wb[7] * b2.v[jx + 1] + wb[8] * b2.v[jx + 2];
-    const float t1 = tanhf(c1), t2 = tanhf(c2);
+    const float t1 = tanh_fast(c1), t2 = tanh_fast(c2);
     const float s1 = t1 + a1.v[jx + 1], s2 = t2 + b1.v[jx + 1];
     const float g = dg.v[jx];
     o.ds1[jx] = g * s2; o.ds2[jx] = g * s1;
@@ -332,10 +352,8 @@ __device__ __forceinline__ GateRow gate_bwd_row(const Row8& a0, const Row8& a1, 
 __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* __restrict__ u, const float* __restrict__ w1,
                                                                    const float* __restrict__ w2, const float* __restrict__ dg,
                                                                    float* __restrict__ du, float* __restrict__ part, int h, int H,
-                                                                   int W, int nchunk) {
+                                                                   int W, int nchunk, Tiling tl) {
   __shared__ float red[kThreads / 64];
-  const int nxg = (((W + 3) >> 2) + 15) >> 4;
-  const int nstrips = (H + kRows - 1) / kRows;
   const long bc = blockIdx.y;                    // b * h + c
   const int c = (int)(bc % h);
   const long b = bc / h;
@@ -356,23 +374,28 @@ __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* 
   for (int t = 0; t < 9; ++t) { acc1[t] = 0.f; acc2[t] = 0.f; }
 
   for (int sub = 0; sub < kSub; ++sub) {
-    const long idx = ((long)blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
-    const int xl = (int)(idx & 15);
-    const long rest = idx >> 4;
-    const int xg = (int)(rest % nxg), strip = (int)(rest / nxg);
-    const int x0 = (xg * 16 + xl) * 4, y0 = strip * kRows;
-    if (!(strip < nstrips && x0 < W)) continue;
-    const int yend = min(y0 + kRows, H);
-    // u windows hold rows r-1, r, r+1 while row r of (da, ds) is being formed
+    const int idx = (blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
+    const int strip = idx / tl.nx4;
+    const int x0 = (idx - strip * tl.nx4) * 4, y0 = strip * tl.rows;
+    if (strip >= tl.nstrips) continue;
+    const int yend = min(y0 + tl.rows, H);
+    // u windows hold rows r-1, r, r+1 while row r of (da, ds) is being formed; the rows the NEXT iteration needs
+    // (u row r+2, dg row r+1) are requested before this iteration's arithmetic, so with only two waves per SIMD
+    // (222 VGPRs) the HBM latency still hides behind ~500 VALU ops
     Row8 a0, a1 = load_row8(p1, y0 - 2, x0, H, W), a2 = load_row8(p1, y0 - 1, x0, H, W);
     Row8 b0, b1 = load_row8(p2, y0 - 2, x0, H, W), b2 = load_row8(p2, y0 - 1, x0, H, W);
+    Row8 na = load_row8(p1, y0, x0, H, W), nb = load_row8(p2, y0, x0, H, W);
+    Row6 ng = load_row6(gp, y0 - 1, x0, H, W);
     GateRow gm, gc;                              // rows r-2 and r-1
 #pragma unroll
     for (int i = 0; i < 6; ++i) { gm.da1[i] = gm.da2[i] = gm.ds1[i] = gm.ds2[i] = 0.f; gc = gm; }
     for (int r = y0 - 1; r <= yend; ++r) {
-      a0 = a1; a1 = a2; a2 = load_row8(p1, r + 1, x0, H, W);
-      b0 = b1; b1 = b2; b2 = load_row8(p2, r + 1, x0, H, W);
-      const Row6 dgr = load_row6(gp, r, x0, H, W);            // zero outside the image => da = ds = 0 there
+      a0 = a1; a1 = a2; a2 = na;
+      b0 = b1; b1 = b2; b2 = nb;
+      const Row6 dgr = ng;                                     // zero outside the image => da = ds = 0 there
+      na = load_row8(p1, r + 2, x0, H, W);
+      nb = load_row8(p2, r + 2, x0, H, W);
+      ng = load_row6(gp, r + 1, x0, H, W);
       const GateRow gn = gate_bwd_row(a0, a1, a2, b0, b1, b2, dgr, wa, wb);
       if (r >= y0 && r < yend) {                               // weight gradients: this lane's own pixels of row r
 #pragma unroll
@@ -436,10 +459,21 @@ __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int B, in
   if (c < csplit) gw1[(long)c * 9 + t] = s; else gw2[(long)(c - csplit) * 9 + t] = s;
 }
 
-inline int wgrad_chunks(int H, int W) {
-  const long nxg = (((W + 3) >> 2) + 15) >> 4;
-  const long nstrips = (H + kRows - 1) / kRows;
-  return (int)((nstrips * nxg * 16 + kThreads - 1) / kThreads);
+// tilings of the kernel families (halo rows re-read per strip: 2 for a stencil, 3 for the fused gate pass;
+// min_lanes = two rounds of the lanes 256 CUs keep resident at each kernel's register footprint)
+inline Tiling fwd_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 2, 256L * 1792 * 2, false); }
+inline Tiling wgrad_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 2, 256L * 1280 * 2, true); }
+inline Tiling gate_bwd_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 3, 256L * 512 * 2, true); }
+
+// block size of a block-per-plane kernel: whole waves, no more than the plane has items
+inline int plane_threads(Tiling tl) {
+  const long items = (long)tl.nstrips * tl.nx4;
+  return items >= kThreads ? kThreads : (int)(((items + 63) / 64) * 64);
+}
+
+inline int chunks_of(Tiling tl) {
+  const int th = plane_threads(tl);
+  return (int)(((long)tl.nstrips * tl.nx4 + th - 1) / th);
 }
 
 }  // namespace
@@ -449,13 +483,16 @@ using namespace cidnet;
 
 extern "C" {
 
+void cidnet_debug_dw_rows(int rows) { g_dw_force_rows = rows; }
+
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend, float* out, int flip,
                  int B, int C, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(in && w1 && out && B > 0 && C > 0 && H > 0 && W > 0);
   CIDNET_CHECK_ARG(csplit >= C || w2);
-  const long items = n_items((long)B * C, H, W);
+  const Tiling tl = fwd_tiling((long)B * C, H, W);
+  const long items = n_items((long)B * C, tl);
   hipLaunchKernelGGL(dw3x3_kernel, dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     (hipStream_t)stream, in, w1, w2, csplit, addend, out, flip, B, C, H, W);
+                     (hipStream_t)stream, in, w1, w2, csplit, addend, out, flip, B, C, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -463,9 +500,10 @@ int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, 
 int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h, int H, int W,
                         void* stream) {
   CIDNET_CHECK_ARG(u && w1 && w2 && g && B > 0 && h > 0 && H > 0 && W > 0);
-  const long items = n_items((long)B * h, H, W);
+  const Tiling tl = fwd_tiling((long)B * h, H, W);
+  const long items = n_items((long)B * h, tl);
   hipLaunchKernelGGL((iel_gate_kernel<0>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     (hipStream_t)stream, u, w1, w2, (const float*)nullptr, g, (float*)nullptr, (float*)nullptr, B, h, H, W);
+                     (hipStream_t)stream, u, w1, w2, (const float*)nullptr, g, (float*)nullptr, (float*)nullptr, B, h, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -473,23 +511,27 @@ int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float*
 int cidnet_iel_gate_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* da, float* ds, int B,
                         int h, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(u && w1 && w2 && dg && da && ds && B > 0 && h > 0 && H > 0 && W > 0);
-  const long items = n_items((long)B * h, H, W);
+  const Tiling tl = fwd_tiling((long)B * h, H, W);
+  const long items = n_items((long)B * h, tl);
   hipLaunchKernelGGL((iel_gate_kernel<1>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     (hipStream_t)stream, u, w1, w2, dg, (float*)nullptr, da, ds, B, h, H, W);
+                     (hipStream_t)stream, u, w1, w2, dg, (float*)nullptr, da, ds, B, h, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
-long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W) { return (long)B * C * wgrad_chunks(H, W) * 9; }
+long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W) {
+  return (long)B * C * chunks_of(wgrad_tiling((long)B * C, H, W)) * 9;
+}
 
 int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw2, int csplit, float* ws, long ws_floats,
                        int B, int C, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(in && gout && gw1 && ws && B > 0 && C > 0 && H > 0 && W > 0);
   CIDNET_CHECK_ARG(csplit >= C || gw2);
   if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
-  const int nchunk = wgrad_chunks(H, W);
-  hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(kThreads), 0, (hipStream_t)stream,
-                     in, gout, ws, H, W, nchunk);
+  const Tiling tl = wgrad_tiling((long)B * C, H, W);
+  const int nchunk = chunks_of(tl);
+  hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream,
+                     in, gout, ws, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B,
                      C, nchunk, gw1, gw2, csplit);
@@ -504,9 +546,10 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
   CIDNET_CHECK_ARG(in && gout && w1 && gin && gw1 && ws && B > 0 && C > 0 && H > 0 && W > 0);
   CIDNET_CHECK_ARG(csplit >= C || (w2 && gw2));
   if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
-  const int nchunk = (wgrad_chunks(H, W) + kSub - 1) / kSub;
-  hipLaunchKernelGGL(dw3x3_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(kThreads), 0, (hipStream_t)stream, in, gout,
-                     w1, w2, csplit, addend, gin, ws, C, H, W, nchunk);
+  const Tiling tl = wgrad_tiling((long)B * C, H, W);
+  const int nchunk = (chunks_of(tl) + kSub - 1) / kSub;
+  hipLaunchKernelGGL(dw3x3_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, in, gout,
+                     w1, w2, csplit, addend, gin, ws, C, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, C,
                      nchunk, gw1, gw2, csplit);
@@ -515,7 +558,7 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
 }
 
 long cidnet_iel_gate_dw_bwd_ws_floats(int B, int h, int H, int W) {
-  return (long)B * h * ((wgrad_chunks(H, W) + kSub - 1) / kSub) * 18;
+  return (long)B * h * ((chunks_of(gate_bwd_tiling((long)B * h, H, W)) + kSub - 1) / kSub) * 18;
 }
 
 /* du = d(loss)/d(u) of the gate INCLUDING the backward of dwconv1/dwconv2, and their weight gradients, in one
@@ -524,9 +567,10 @@ int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, con
                            float* ws, long ws_floats, int B, int h, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(u && w1 && w2 && dg && du && gw1 && gw2 && ws && B > 0 && h > 0 && H > 0 && W > 0);
   if (ws_floats < cidnet_iel_gate_dw_bwd_ws_floats(B, h, H, W)) return CIDNET_ERR_WS;
-  const int nchunk = (wgrad_chunks(H, W) + kSub - 1) / kSub;
-  hipLaunchKernelGGL(iel_gate_dw_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * h)), dim3(kThreads), 0, (hipStream_t)stream, u,
-                     w1, w2, dg, du, ws, h, H, W, nchunk);
+  const Tiling tl = gate_bwd_tiling((long)B * h, H, W);
+  const int nchunk = (chunks_of(tl) + kSub - 1) / kSub;
+  hipLaunchKernelGGL(iel_gate_dw_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * h)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, u,
+                     w1, w2, dg, du, ws, h, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((h * 18 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, h,
                      nchunk, gw1, gw2);

@@ -108,33 +108,40 @@ __global__ void bilinear_tab_kernel(int* __restrict__ idx, float* __restrict__ w
 }
 
 // din[pl][yi][xi] = sum over table taps of wy * wx * dout[pl][yo][xo]   (gather: no atomics)
+// A lane owns one input column xi: its x taps are read once into registers and reused for every row the wave
+// visits; a wave owns whole input rows (grid-stride over planes * Hi), so the y taps are wave-uniform (scalar
+// loads, uniform early exit) and a row's KX gathers hit neighbouring addresses across the wave.  KX bounds the
+// x taps of this launch (2 for the x0.5 adjoint, up to kTabK for x2); unused table slots hold (index 0, weight 0).
+template <int KX>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
                                                                 const int* __restrict__ yidx, const float* __restrict__ ywgt,
                                                                 const int* __restrict__ xidx, const float* __restrict__ xwgt,
-                                                                long planes, int Hi, int Wi, int Ho, int Wo) {
-  const long total = planes * Hi * Wi;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int xi = (int)(i % Wi);
-    const int yi = (int)((i / Wi) % Hi);
-    const long pl = i / ((long)Wi * Hi);
-    const float* g = dout + pl * (long)Ho * Wo;
-    int xo[kTabK];
-    float xw[kTabK];
+                                                                long nrows, int Hi, int Wi, int Ho, int Wo) {
+  const int xi = blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool live = xi < Wi;
+  int xo[KX];
+  float xw[KX];
 #pragma unroll
-    for (int k = 0; k < kTabK; ++k) { xo[k] = xidx[xi * kTabK + k]; xw[k] = xwgt[xi * kTabK + k]; }
+  for (int k = 0; k < KX; ++k) {
+    xo[k] = live ? xidx[xi * kTabK + k] : 0;
+    xw[k] = live ? xwgt[xi * kTabK + k] : 0.f;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long stride = (long)gridDim.y * (kThreads / 64);
+  for (long r = (long)blockIdx.y * (kThreads / 64) + wave; r < nrows; r += stride) {
+    const int yi = (int)(r % Hi);
+    const float* g = dout + (r / Hi) * (long)Ho * Wo;
     float s = 0.f;
-#pragma unroll
     for (int ky = 0; ky < kTabK; ++ky) {
       const float wy = ywgt[yi * kTabK + ky];
-      if (wy == 0.f) continue;
+      if (wy == 0.f) break;                                  // taps are packed at the front of a table row
       const float* row = g + (long)yidx[yi * kTabK + ky] * Wo;
       float rs = 0.f;
 #pragma unroll
-      for (int k = 0; k < kTabK; ++k)
-        if (xw[k] != 0.f) rs += xw[k] * row[xo[k]];
+      for (int k = 0; k < KX; ++k) rs += xw[k] * row[xo[k]];
       s += wy * rs;
     }
-    din[i] = s;
+    if (live) din[r * Wi + xi] = s;
   }
 }
 
@@ -204,9 +211,22 @@ int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(bilinear_tab_kernel, dim3((Wi + 255) / 256), dim3(256), 0, s, xidx, xwgt, Wi, Wo);
   CIDNET_LAUNCH_STATUS();
-  const long planes = (long)B * C;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(planes * Hi * Wi, 16384)), dim3(kThreads), 0, s, dout, din, yidx, ywgt,
-                     xidx, xwgt, planes, Hi, Wi, Ho, Wo);
+  // x taps of one input column: outputs o with floor(o * s) in {i-1, i}, s = (in-1)/(out-1): at most floor(2/s) + 1
+  const double sx = Wo > 1 ? (double)(Wi - 1) / (double)(Wo - 1) : 0.0;
+  const int kx = sx > 0.0 ? (int)(2.0 / sx + 1e-3) + 1 : kTabK;
+  const long nrows = (long)B * C * Hi;
+  const int gx = (Wi + 63) / 64;
+  long gy = (nrows + kThreads / 64 - 1) / (kThreads / 64);
+  const long cap = 16384 / gx > 0 ? 16384 / gx : 1;
+  if (gy > cap) gy = cap;
+  const dim3 grid((unsigned)gx, (unsigned)gy);
+  if (kx <= 2)
+    hipLaunchKernelGGL((bilinear_bwd_kernel<2>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho, Wo);
+  else if (kx <= 3)
+    hipLaunchKernelGGL((bilinear_bwd_kernel<3>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho, Wo);
+  else
+    hipLaunchKernelGGL((bilinear_bwd_kernel<kTabK>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho,
+                       Wo);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

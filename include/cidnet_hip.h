@@ -97,6 +97,8 @@ int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, floa
 /* ---- K5 / K8: depthwise 3x3 (zero pad) and the IEL gate  (net/LCA.py:14,16,53-55,62-65) --------
  * out = dw3x3(in) [+ addend]; channel c uses w1[c] if c < csplit else w2[c-csplit] (weights (.,1,3,3));
  * flip != 0 applies the 180-degree rotated taps (= data gradient of the forward). */
+/* timing-study switch: force the strip height of the depthwise / gate kernels (0 = automatic) */
+void cidnet_debug_dw_rows(int rows);
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend,
                  float* out, int flip, int B, int C, int H, int W, void* stream);
 long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W);

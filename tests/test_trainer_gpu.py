@@ -49,17 +49,33 @@ def test_trainer_gradients_and_update_match_plain_autograd(dev, chans, shape):
         got = tr.flat_g[off:off + cnt].view(p.shape)
         ref_g = grads[n]
         tol = 1e-5 * ref_g.abs().max().item() + 1e-8
-        assert (got - ref_g).abs().max().item() <= tol, n
+        err = (got - ref_g).abs().max().item()
+        assert err <= tol, f"{n}: {err:.3e} > {tol:.3e}"
         checked += 1
     assert checked > 150
-    # one full step == torch Adam on the reference model
+    # one full step == torch Adam fed with the harness's own gradients.  (Fed with the plain-autograd gradients
+    # instead, first-step Adam ~ lr * g / (|g| + eps) amplifies summation-order noise on elements with
+    # |g| ~ eps into differences of the order of lr, so that comparison would test luck.)
     ops.set_grad_arena(None, None)
     ops.enable_wgrad_stream(False)
     m2 = _model(dev, chans)
+    before = {n: p.detach().clone() for n, p in m2.named_parameters()}
     tr2 = DataParallelTrainer(m2, lr=1e-3, n_buckets=3)
     tr2.step(x, gt)
     torch.cuda.synchronize()
-    for (n, a), (_, b) in zip(m2.named_parameters(), ref.named_parameters()):
-        assert torch.allclose(a, b, atol=2e-6, rtol=1e-5), n
+    twins = []
+    for n, p in m2.named_parameters():
+        if n not in grads:
+            assert torch.equal(p, before[n]), n              # dead I_LCA5.*: untouched
+            continue
+        off, cnt = tr2._slices[id(p)]
+        g2 = tr2.flat_g[off:off + cnt].view(p.shape)
+        assert (g2 - grads[n]).abs().max().item() <= 1e-5 * grads[n].abs().max().item() + 1e-8, n
+        t = before[n].clone().requires_grad_(True)
+        t.grad = g2.clone()
+        twins.append((n, p, t))
+    torch.optim.Adam([t for _, _, t in twins], lr=1e-3).step()
+    for n, p, t in twins:
+        assert torch.allclose(p, t, atol=1e-7, rtol=1e-6), n
     ops.set_grad_arena(None, None)
     ops.enable_wgrad_stream(False)
