@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--width", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
+    ap.add_argument("--op-rows", type=int, default=70, help="rows of the per-shape part of --op-table")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the I and HV branches on one stream (default: two streams, kernels of the two branches overlap)")
     return ap.parse_args()
@@ -159,7 +160,7 @@ def main():
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {k:40s} calls/step {v[0] // 2:5d}  ms/step {v[1] / 2:9.3f}  {100 * v[1] / tot:5.1f}%", file=sys.stderr)
             print(f"  sum of kernel families: {tot / 2:.3f} ms/step; wall {1e3 * dt / a.steps:.3f} ms/step", file=sys.stderr)
-            for k, v in sorted(timer.table(by_shape=True).items(), key=lambda kv: -kv[1][1])[:70]:
+            for k, v in sorted(timer.table(by_shape=True).items(), key=lambda kv: -kv[1][1])[:a.op_rows]:
                 print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
         roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad)",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -14,6 +14,7 @@
 //   Weights (A operand) are staged per 16-channel chunk in LDS as [ci][tap][co] with a leading
 //   dimension == 16 (mod 32): conflict-free ds_read_b32.
 #include "common.h"
+#include "conv3_thin.h"
 
 namespace cidnet {
 namespace {
@@ -474,6 +475,8 @@ int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w
   C3Args a{};
   a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs;
   a.M = M; a.K = K; a.H = H; a.W = W; a.flip = flip; a.replicate = replicate; a.dbg = g_c3_dbg;
+  if (c3_thin_applies(M, K) && !(g_c3_dbg & 8))
+    return c3_thin_conv(X, x_bs, Wt, w_ms, w_ks, flip, replicate, Y, y_bs, B, M, K, H, W, (hipStream_t)stream);
   const int T = (M + 15) / 16;
   const int nblk = (T + 2) / 3;
   const int MT = (T + nblk - 1) / nblk;
@@ -487,6 +490,7 @@ int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w
 }
 
 long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W) {
+  if (c3_thin_applies(M, N) && !(g_c3_dbg & 8)) return (long)B * c3_thin_wgrad_chunks(H, W) * M * N * 9;
   const int rr = wg_rows(B, M, N, H, W);
   const long chunks = (long)(((W + 31) / 32 + 3) / 4) * ((H + rr - 1) / rr);
   return (long)B * chunks * M * N * 9;
@@ -496,6 +500,15 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
                          long ws_floats, int B, int M, int N, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && H > 0 && W > 0);
   if (ws_floats < cidnet_conv3x3_wgrad_ws_floats(B, M, N, H, W)) return CIDNET_ERR_WS;
+  if (c3_thin_applies(M, N) && !(g_c3_dbg & 8)) {
+    const int rc = c3_thin_wgrad(dY, dy_bs, X, x_bs, replicate, ws, B, M, N, H, W, (hipStream_t)stream);
+    if (rc != CIDNET_OK) return rc;
+    const long ne = (long)M * N * 9;
+    hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, (hipStream_t)stream, ws,
+                       B * c3_thin_wgrad_chunks(H, W), ne, dW);
+    CIDNET_LAUNCH_STATUS();
+    return CIDNET_OK;
+  }
   C3WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.H = H; a.W = W;
   a.replicate = replicate; a.rr = wg_rows(B, M, N, H, W);

@@ -9,6 +9,7 @@
 // two), then the next strip.  The strip height is picked per launch (pick_tiling): as tall as the
 // plane count allows, because every strip re-reads its halo rows.  HBM-bound by construction.
 #include "common.h"
+#include "stencil.h"
 
 namespace cidnet {
 namespace {
@@ -17,42 +18,7 @@ constexpr int kThreads = 256;
 constexpr int kMinRows = 8, kMaxRows = 24;
 constexpr int kSub = 4;     // 256-item groups a fused-backward block walks before reducing
 
-struct Row6 {
-  float v[6];
-};
-
-// pixels x0-1 .. x0+4 of row yy of a plane (zero outside the image)
-__device__ __forceinline__ Row6 load_row6(const float* __restrict__ plane, int yy, int x0, int H, int W) {
-  Row6 r;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) r.v[i] = 0.f;
-  if (yy < 0 || yy >= H) return r;
-  const float* row = plane + (long)yy * W;
-  if (x0 + 3 < W) {
-    const f32x4 m = load4u(row + x0);
-    r.v[1] = m[0]; r.v[2] = m[1]; r.v[3] = m[2]; r.v[4] = m[3];
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (x0 + e < W) r.v[1 + e] = row[x0 + e];
-  }
-  if (x0 > 0) r.v[0] = row[x0 - 1];
-  if (x0 + 4 < W) r.v[5] = row[x0 + 4];
-  return r;
-}
-
-__device__ __forceinline__ void store_row4(float* __restrict__ plane, int y, int x0, int W, f32x4 v) {
-  float* row = plane + (long)y * W;
-  if (x0 + 3 < W) {
-    store4u(row + x0, v);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (x0 + e < W) row[x0 + e] = v[e];
-  }
-}
-
-__device__ __forceinline__ f32x4 stencil(const Row6& a, const Row6& b, const Row6& c, const float* w) {
+__device__ __forceinline__ f32x4 stencil(const Win6& a, const Win6& b, const Win6& c, const float* w) {
   f32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -63,7 +29,7 @@ __device__ __forceinline__ f32x4 stencil(const Row6& a, const Row6& b, const Row
 
 struct Item {
   long bc;
-  int y0, x0;
+  int y0, x0, dup;
   bool live;
 };
 
@@ -74,6 +40,7 @@ struct Tiling {
 };
 
 // flattened work decomposition: (bc * nstrips + strip) * nx4 + xl
+template <bool NARROW>
 __device__ __forceinline__ Item decode_item(long planes, Tiling tl, int W) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   Item it;
@@ -82,7 +49,7 @@ __device__ __forceinline__ Item decode_item(long planes, Tiling tl, int W) {
   const long strip = rest % tl.nstrips;
   it.bc = rest / tl.nstrips;
   it.y0 = (int)strip * tl.rows;
-  it.x0 = (int)xl * 4;
+  it.x0 = lane_x0<NARROW>((int)xl, W, it.dup);
   it.live = it.bc < planes;
   return it;
 }
@@ -123,11 +90,12 @@ __device__ __forceinline__ void load_w9(const float* w1, const float* w2, int cs
 }
 
 // out = dwconv3x3(in) [+ addend]
+template <bool NARROW>
 __global__ __launch_bounds__(kThreads) void dw3x3_kernel(const float* __restrict__ in, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, int csplit,
                                                          const float* __restrict__ addend, float* __restrict__ out, int flip,
                                                          int B, int C, int H, int W, Tiling tl) {
-  const Item it = decode_item((long)B * C, tl, W);
+  const Item it = decode_item<NARROW>((long)B * C, tl, W);
   if (!it.live) return;
   float w[9];
   load_w9(w1, w2, csplit, (int)(it.bc % C), flip != 0, w);
@@ -135,29 +103,28 @@ __global__ __launch_bounds__(kThreads) void dw3x3_kernel(const float* __restrict
   const float* ip = in + it.bc * HW;
   float* op = out + it.bc * HW;
   const float* ap = addend ? addend + it.bc * HW : nullptr;
-  Row6 r0 = load_row6(ip, it.y0 - 1, it.x0, H, W);
-  Row6 r1 = load_row6(ip, it.y0, it.x0, H, W);
+  Win6 r0 = load_win6<false, NARROW>(ip, it.y0 - 1, it.x0, H, W);
+  Win6 r1 = load_win6<false, NARROW>(ip, it.y0, it.x0, H, W);
   const int yend = min(it.y0 + tl.rows, H);
   for (int y = it.y0; y < yend; ++y) {
-    const Row6 r2 = load_row6(ip, y + 1, it.x0, H, W);
+    const Win6 r2 = load_win6<false, NARROW>(ip, y + 1, it.x0, H, W);
     f32x4 o = stencil(r0, r1, r2, w);
     if (ap) {
-      const Row6 a = load_row6(ap, y, it.x0, H, W);
-      o[0] += a.v[1]; o[1] += a.v[2]; o[2] += a.v[3]; o[3] += a.v[4];
+      o += load_px4<NARROW>(ap, y, it.x0, W);
     }
-    store_row4(op, y, it.x0, W, o);
+    store_px4<NARROW>(op, y, it.x0, W, o);
     r0 = r1; r1 = r2;
   }
 }
 
 // IEL gate.  u: (B, 2h, H, W); channel c pairs u1 = u[c], u2 = u[h + c].
 // MODE 0: g = s1*s2.   MODE 1 (backward): da = dg * s_other * (1 - t^2), ds = dg * s_other.
-template <int MODE>
+template <int MODE, bool NARROW>
 __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restrict__ u, const float* __restrict__ w1,
                                                             const float* __restrict__ w2, const float* __restrict__ dg,
                                                             float* __restrict__ g, float* __restrict__ da,
                                                             float* __restrict__ ds, int B, int h, int H, int W, Tiling tl) {
-  const Item it = decode_item((long)B * h, tl, W);
+  const Item it = decode_item<NARROW>((long)B * h, tl, W);
   if (!it.live) return;
   const int c = (int)(it.bc % h);
   const long b = it.bc / h;
@@ -167,12 +134,12 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
   const long HW = (long)H * W;
   const float* p1 = u + (b * 2 * h + c) * HW;
   const float* p2 = u + (b * 2 * h + h + c) * HW;
-  Row6 a0 = load_row6(p1, it.y0 - 1, it.x0, H, W), a1 = load_row6(p1, it.y0, it.x0, H, W);
-  Row6 b0 = load_row6(p2, it.y0 - 1, it.x0, H, W), b1 = load_row6(p2, it.y0, it.x0, H, W);
+  Win6 a0 = load_win6<false, NARROW>(p1, it.y0 - 1, it.x0, H, W), a1 = load_win6<false, NARROW>(p1, it.y0, it.x0, H, W);
+  Win6 b0 = load_win6<false, NARROW>(p2, it.y0 - 1, it.x0, H, W), b1 = load_win6<false, NARROW>(p2, it.y0, it.x0, H, W);
   const int yend = min(it.y0 + tl.rows, H);
   for (int y = it.y0; y < yend; ++y) {
-    const Row6 a2 = load_row6(p1, y + 1, it.x0, H, W);
-    const Row6 b2 = load_row6(p2, y + 1, it.x0, H, W);
+    const Win6 a2 = load_win6<false, NARROW>(p1, y + 1, it.x0, H, W);
+    const Win6 b2 = load_win6<false, NARROW>(p2, y + 1, it.x0, H, W);
     const f32x4 c1 = stencil(a0, a1, a2, wa), c2 = stencil(b0, b1, b2, wb);
     f32x4 t1, t2, s1, s2;
 #pragma unroll
@@ -181,32 +148,34 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
       s1[e] = t1[e] + a1.v[1 + e]; s2[e] = t2[e] + b1.v[1 + e];
     }
     if (MODE == 0) {
-      store_row4(g + it.bc * HW, y, it.x0, W, s1 * s2);
+      store_px4<NARROW>(g + it.bc * HW, y, it.x0, W, s1 * s2);
     } else {
-      const Row6 gr = load_row6(dg + it.bc * HW, y, it.x0, H, W);
+      const Win6 gr = load_win6<false, NARROW>(dg + it.bc * HW, y, it.x0, H, W);
       f32x4 d1, d2, e1, e2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         d1[e] = gr.v[1 + e] * s2[e]; d2[e] = gr.v[1 + e] * s1[e];
         e1[e] = d1[e] * (1.f - t1[e] * t1[e]); e2[e] = d2[e] * (1.f - t2[e] * t2[e]);
       }
-      store_row4(ds + (b * 2 * h + c) * HW, y, it.x0, W, d1);
-      store_row4(ds + (b * 2 * h + h + c) * HW, y, it.x0, W, d2);
-      store_row4(da + (b * 2 * h + c) * HW, y, it.x0, W, e1);
-      store_row4(da + (b * 2 * h + h + c) * HW, y, it.x0, W, e2);
+      store_px4<NARROW>(ds + (b * 2 * h + c) * HW, y, it.x0, W, d1);
+      store_px4<NARROW>(ds + (b * 2 * h + h + c) * HW, y, it.x0, W, d2);
+      store_px4<NARROW>(da + (b * 2 * h + c) * HW, y, it.x0, W, e1);
+      store_px4<NARROW>(da + (b * 2 * h + h + c) * HW, y, it.x0, W, e2);
     }
     a0 = a1; a1 = a2; b0 = b1; b1 = b2;
   }
 }
 
 // gw[c][t] partial over one block of strips of plane (b,c):  sum gout[y][x] * in[y+dy-1][x+dx-1]
+template <bool NARROW>
 __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                                float* __restrict__ part, int H, int W, int nchunk, Tiling tl) {
   __shared__ float red[kThreads / 64];
   const long bc = blockIdx.y;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // item inside the plane
   const int strip = idx / tl.nx4;
-  const int x0 = (idx - strip * tl.nx4) * 4, y0 = strip * tl.rows;
+  int dup;
+  const int x0 = lane_x0<NARROW>(idx - strip * tl.nx4, W, dup), y0 = strip * tl.rows;
   const bool live = strip < tl.nstrips;
   float acc[9];
 #pragma unroll
@@ -215,14 +184,14 @@ __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __re
     const long HW = (long)H * W;
     const float* ip = in + bc * HW;
     const float* gp = gout + bc * HW;
-    Row6 r0 = load_row6(ip, y0 - 1, x0, H, W), r1 = load_row6(ip, y0, x0, H, W);
+    Win6 r0 = load_win6<false, NARROW>(ip, y0 - 1, x0, H, W), r1 = load_win6<false, NARROW>(ip, y0, x0, H, W);
     const int yend = min(y0 + tl.rows, H);
     for (int y = y0; y < yend; ++y) {
-      const Row6 r2 = load_row6(ip, y + 1, x0, H, W);
-      const Row6 gr = load_row6(gp, y, x0, H, W);
+      const Win6 r2 = load_win6<false, NARROW>(ip, y + 1, x0, H, W);
+      const Win6 gr = load_win6<false, NARROW>(gp, y, x0, H, W);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float gv = gr.v[1 + e];
+        const float gv = e < dup ? 0.f : gr.v[1 + e];
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           acc[dx] += gv * r0.v[e + dx]; acc[3 + dx] += gv * r1.v[e + dx]; acc[6 + dx] += gv * r2.v[e + dx];
@@ -242,6 +211,7 @@ __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __re
 //   gin[y][x] = sum_tap w[8-tap] * gout[y+dy-1][x+dx-1]  (+ addend)
 // and the per-block partial of the weight gradient gw[tap] = sum gout[y][x] * in[y+dy-1][x+dx-1]:
 // gout is read once instead of twice (3 tensor passes instead of 4).
+template <bool NARROW>
 __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                              const float* __restrict__ w1, const float* __restrict__ w2, int csplit,
                                                              const float* __restrict__ addend, float* __restrict__ gin,
@@ -263,23 +233,23 @@ __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __rest
   for (int sub = 0; sub < kSub; ++sub) {
     const int idx = (blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
     const int strip = idx / tl.nx4;
-    const int x0 = (idx - strip * tl.nx4) * 4, y0 = strip * tl.rows;
+    int dup;
+    const int x0 = lane_x0<NARROW>(idx - strip * tl.nx4, W, dup), y0 = strip * tl.rows;
     if (strip >= tl.nstrips) continue;
-    Row6 i0 = load_row6(ip, y0 - 1, x0, H, W), i1 = load_row6(ip, y0, x0, H, W);
-    Row6 g0 = load_row6(gp, y0 - 1, x0, H, W), g1 = load_row6(gp, y0, x0, H, W);
+    Win6 i0 = load_win6<false, NARROW>(ip, y0 - 1, x0, H, W), i1 = load_win6<false, NARROW>(ip, y0, x0, H, W);
+    Win6 g0 = load_win6<false, NARROW>(gp, y0 - 1, x0, H, W), g1 = load_win6<false, NARROW>(gp, y0, x0, H, W);
     const int yend = min(y0 + tl.rows, H);
     for (int y = y0; y < yend; ++y) {
-      const Row6 i2 = load_row6(ip, y + 1, x0, H, W);
-      const Row6 g2 = load_row6(gp, y + 1, x0, H, W);
+      const Win6 i2 = load_win6<false, NARROW>(ip, y + 1, x0, H, W);
+      const Win6 g2 = load_win6<false, NARROW>(gp, y + 1, x0, H, W);
       f32x4 o = stencil(g0, g1, g2, w);
       if (ap) {
-        const Row6 a = load_row6(ap, y, x0, H, W);
-        o[0] += a.v[1]; o[1] += a.v[2]; o[2] += a.v[3]; o[3] += a.v[4];
+        o += load_px4<NARROW>(ap, y, x0, W);
       }
-      store_row4(op, y, x0, W, o);
+      store_px4<NARROW>(op, y, x0, W, o);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float gv = g1.v[1 + e];
+        const float gv = e < dup ? 0.f : g1.v[1 + e];
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           acc[dx] += gv * i0.v[e + dx]; acc[3 + dx] += gv * i1.v[e + dx]; acc[6 + dx] += gv * i2.v[e + dx];
@@ -303,36 +273,12 @@ __global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __rest
 // The unfused path wrote da, ds (4h channels) and read them back (plus u again) in a second kernel; here a
 // lane recomputes da on its strip plus a one-pixel halo from an 8-wide register window of u, so the only
 // HBM traffic is: read dg (h), read u (2h), write du (2h).  One lane = one channel pair, 4 px x `rows` rows.
-struct Row8 {
-  float v[8];
-};
-// pixels x0-2 .. x0+5 of row yy of a plane (zero outside the image)
-__device__ __forceinline__ Row8 load_row8(const float* __restrict__ plane, int yy, int x0, int H, int W) {
-  Row8 r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
-  if (yy < 0 || yy >= H) return r;
-  const float* row = plane + (long)yy * W;
-  if (x0 >= 2 && x0 + 6 <= W) {
-    const f32x4 a = load4u(row + x0 - 2), b = load4u(row + x0 + 2);
-    r.v[0] = a[0]; r.v[1] = a[1]; r.v[2] = a[2]; r.v[3] = a[3];
-    r.v[4] = b[0]; r.v[5] = b[1]; r.v[6] = b[2]; r.v[7] = b[3];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int x = x0 - 2 + i;
-      if (x >= 0 && x < W) r.v[i] = row[x];
-    }
-  }
-  return r;
-}
-
 struct GateRow {      // da, ds of one row on the 6-wide window x0-1 .. x0+4, for both channels of the pair
   float da1[6], da2[6], ds1[6], ds2[6];
 };
 
-__device__ __forceinline__ GateRow gate_bwd_row(const Row8& a0, const Row8& a1, const Row8& a2, const Row8& b0, const Row8& b1,
-                                                const Row8& b2, const Row6& dg, const float* wa, const float* wb) {
+__device__ __forceinline__ GateRow gate_bwd_row(const Win8& a0, const Win8& a1, const Win8& a2, const Win8& b0, const Win8& b1,
+                                                const Win8& b2, const Win6& dg, const float* wa, const float* wb) {
   GateRow o;
 #pragma unroll
   for (int jx = 0; jx < 6; ++jx) {
@@ -349,6 +295,7 @@ __device__ __forceinline__ GateRow gate_bwd_row(const Row8& a0, const Row8& a1, 
   return o;
 }
 
+template <bool NARROW>
 __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* __restrict__ u, const float* __restrict__ w1,
                                                                    const float* __restrict__ w2, const float* __restrict__ dg,
                                                                    float* __restrict__ du, float* __restrict__ part, int h, int H,
@@ -376,31 +323,32 @@ __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* 
   for (int sub = 0; sub < kSub; ++sub) {
     const int idx = (blockIdx.x * kSub + sub) * blockDim.x + threadIdx.x;
     const int strip = idx / tl.nx4;
-    const int x0 = (idx - strip * tl.nx4) * 4, y0 = strip * tl.rows;
+    int dup;
+    const int x0 = lane_x0<NARROW>(idx - strip * tl.nx4, W, dup), y0 = strip * tl.rows;
     if (strip >= tl.nstrips) continue;
     const int yend = min(y0 + tl.rows, H);
     // u windows hold rows r-1, r, r+1 while row r of (da, ds) is being formed; the rows the NEXT iteration needs
     // (u row r+2, dg row r+1) are requested before this iteration's arithmetic, so with only two waves per SIMD
     // (222 VGPRs) the HBM latency still hides behind ~500 VALU ops
-    Row8 a0, a1 = load_row8(p1, y0 - 2, x0, H, W), a2 = load_row8(p1, y0 - 1, x0, H, W);
-    Row8 b0, b1 = load_row8(p2, y0 - 2, x0, H, W), b2 = load_row8(p2, y0 - 1, x0, H, W);
-    Row8 na = load_row8(p1, y0, x0, H, W), nb = load_row8(p2, y0, x0, H, W);
-    Row6 ng = load_row6(gp, y0 - 1, x0, H, W);
+    Win8 a0, a1 = load_win8<NARROW>(p1, y0 - 2, x0, H, W), a2 = load_win8<NARROW>(p1, y0 - 1, x0, H, W);
+    Win8 b0, b1 = load_win8<NARROW>(p2, y0 - 2, x0, H, W), b2 = load_win8<NARROW>(p2, y0 - 1, x0, H, W);
+    Win8 na = load_win8<NARROW>(p1, y0, x0, H, W), nb = load_win8<NARROW>(p2, y0, x0, H, W);
+    Win6 ng = load_win6<false, NARROW>(gp, y0 - 1, x0, H, W);
     GateRow gm, gc;                              // rows r-2 and r-1
 #pragma unroll
     for (int i = 0; i < 6; ++i) { gm.da1[i] = gm.da2[i] = gm.ds1[i] = gm.ds2[i] = 0.f; gc = gm; }
     for (int r = y0 - 1; r <= yend; ++r) {
       a0 = a1; a1 = a2; a2 = na;
       b0 = b1; b1 = b2; b2 = nb;
-      const Row6 dgr = ng;                                     // zero outside the image => da = ds = 0 there
-      na = load_row8(p1, r + 2, x0, H, W);
-      nb = load_row8(p2, r + 2, x0, H, W);
-      ng = load_row6(gp, r + 1, x0, H, W);
+      const Win6 dgr = ng;                                     // zero outside the image => da = ds = 0 there
+      na = load_win8<NARROW>(p1, r + 2, x0, H, W);
+      nb = load_win8<NARROW>(p2, r + 2, x0, H, W);
+      ng = load_win6<false, NARROW>(gp, r + 1, x0, H, W);
       const GateRow gn = gate_bwd_row(a0, a1, a2, b0, b1, b2, dgr, wa, wb);
       if (r >= y0 && r < yend) {                               // weight gradients: this lane's own pixels of row r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float d1 = gn.da1[e + 1], d2 = gn.da2[e + 1];
+          const float d1 = e < dup ? 0.f : gn.da1[e + 1], d2 = e < dup ? 0.f : gn.da2[e + 1];
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
             acc1[dx] += d1 * a0.v[e + dx + 1]; acc1[3 + dx] += d1 * a1.v[e + dx + 1]; acc1[6 + dx] += d1 * a2.v[e + dx + 1];
@@ -418,8 +366,8 @@ __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* 
           d2[e] = gc.ds2[e + 1] + fb[0] * gm.da2[e] + fb[1] * gm.da2[e + 1] + fb[2] * gm.da2[e + 2] + fb[3] * gc.da2[e] +
                   fb[4] * gc.da2[e + 1] + fb[5] * gc.da2[e + 2] + fb[6] * gn.da2[e] + fb[7] * gn.da2[e + 1] + fb[8] * gn.da2[e + 2];
         }
-        store_row4(o1, q, x0, W, d1);
-        store_row4(o2, q, x0, W, d2);
+        store_px4<NARROW>(o1, q, x0, W, d1);
+        store_px4<NARROW>(o2, q, x0, W, d2);
       }
       gm = gc; gc = gn;
     }
@@ -481,6 +429,13 @@ inline int chunks_of(Tiling tl) {
 
 using namespace cidnet;
 
+// launch KERNEL<..., NARROW> with NARROW = (W < 8): the generic per-element loaders only exist in that instantiation
+#define CIDNET_LAUNCH_NW(W_, KERNEL_T, KERNEL_F, ...)                    \
+  do {                                                                   \
+    if ((W_) < 8) hipLaunchKernelGGL(KERNEL_T, __VA_ARGS__);             \
+    else hipLaunchKernelGGL(KERNEL_F, __VA_ARGS__);                      \
+  } while (0)
+
 extern "C" {
 
 void cidnet_debug_dw_rows(int rows) { g_dw_force_rows = rows; }
@@ -491,7 +446,7 @@ int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, 
   CIDNET_CHECK_ARG(csplit >= C || w2);
   const Tiling tl = fwd_tiling((long)B * C, H, W);
   const long items = n_items((long)B * C, tl);
-  hipLaunchKernelGGL(dw3x3_kernel, dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+  CIDNET_LAUNCH_NW(W, (dw3x3_kernel<true>), (dw3x3_kernel<false>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      (hipStream_t)stream, in, w1, w2, csplit, addend, out, flip, B, C, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
@@ -502,7 +457,7 @@ int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float*
   CIDNET_CHECK_ARG(u && w1 && w2 && g && B > 0 && h > 0 && H > 0 && W > 0);
   const Tiling tl = fwd_tiling((long)B * h, H, W);
   const long items = n_items((long)B * h, tl);
-  hipLaunchKernelGGL((iel_gate_kernel<0>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+  CIDNET_LAUNCH_NW(W, (iel_gate_kernel<0, true>), (iel_gate_kernel<0, false>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      (hipStream_t)stream, u, w1, w2, (const float*)nullptr, g, (float*)nullptr, (float*)nullptr, B, h, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
@@ -513,7 +468,7 @@ int cidnet_iel_gate_bwd(const float* u, const float* w1, const float* w2, const 
   CIDNET_CHECK_ARG(u && w1 && w2 && dg && da && ds && B > 0 && h > 0 && H > 0 && W > 0);
   const Tiling tl = fwd_tiling((long)B * h, H, W);
   const long items = n_items((long)B * h, tl);
-  hipLaunchKernelGGL((iel_gate_kernel<1>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+  CIDNET_LAUNCH_NW(W, (iel_gate_kernel<1, true>), (iel_gate_kernel<1, false>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      (hipStream_t)stream, u, w1, w2, dg, (float*)nullptr, da, ds, B, h, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
@@ -530,7 +485,7 @@ int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw
   if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
   const Tiling tl = wgrad_tiling((long)B * C, H, W);
   const int nchunk = chunks_of(tl);
-  hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream,
+  CIDNET_LAUNCH_NW(W, (dw3x3_wgrad_kernel<true>), (dw3x3_wgrad_kernel<false>), dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream,
                      in, gout, ws, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B,
@@ -548,7 +503,7 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
   if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
   const Tiling tl = wgrad_tiling((long)B * C, H, W);
   const int nchunk = (chunks_of(tl) + kSub - 1) / kSub;
-  hipLaunchKernelGGL(dw3x3_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, in, gout,
+  CIDNET_LAUNCH_NW(W, (dw3x3_bwd_kernel<true>), (dw3x3_bwd_kernel<false>), dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, in, gout,
                      w1, w2, csplit, addend, gin, ws, C, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, C,
@@ -569,7 +524,7 @@ int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, con
   if (ws_floats < cidnet_iel_gate_dw_bwd_ws_floats(B, h, H, W)) return CIDNET_ERR_WS;
   const Tiling tl = gate_bwd_tiling((long)B * h, H, W);
   const int nchunk = (chunks_of(tl) + kSub - 1) / kSub;
-  hipLaunchKernelGGL(iel_gate_dw_bwd_kernel, dim3((unsigned)nchunk, (unsigned)(B * h)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, u,
+  CIDNET_LAUNCH_NW(W, (iel_gate_dw_bwd_kernel<true>), (iel_gate_dw_bwd_kernel<false>), dim3((unsigned)nchunk, (unsigned)(B * h)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, u,
                      w1, w2, dg, du, ws, h, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((h * 18 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, h,

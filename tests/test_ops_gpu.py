@@ -101,7 +101,9 @@ def test_dw3x3(dev, B, C, H, W):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,rep", [(2, 36, 36, 16, 24, False), (1, 72, 144, 10, 15, False), (1, 12, 24, 9, 70, False),
                                              (2, 3, 36, 16, 24, True), (2, 36, 2, 13, 19, True), (1, 1, 36, 8, 8, True),
-                                             (1, 36, 1, 8, 72, True), (1, 144, 72, 50, 75, False)])
+                                             (1, 36, 1, 8, 72, True), (1, 144, 72, 50, 75, False),
+                                             (2, 4, 36, 21, 37, False), (1, 36, 3, 40, 50, False), (2, 3, 36, 40, 50, True),
+                                             (1, 36, 4, 35, 21, True), (1, 2, 20, 33, 600, True)])
 def test_conv3x3(dev, B, Ci, Co, H, W, rep):
     from hvi_cidnet_amd import ops
     x, w = rnd(21, (B, Ci, H, W)), rnd(22, (Co, Ci, 3, 3), 0.3)
