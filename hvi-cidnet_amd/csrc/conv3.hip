@@ -11,6 +11,11 @@
 //   6-wide window is the B operand (k = j, col = c) of the MFMA for tap (dy,dx) and pixel slot e, so
 //   the accumulators e = 0..3 of an output channel hold 4 consecutive pixels: float4 stores.
 //   One loaded input row feeds up to 3 output rows x 3 dx x 4 slots x MT channel tiles of MFMAs.
+//   Output channels that do not fill a 16-row tile: up to two groups of 4 rows per block go through
+//   v_mfma_f32_4x4x1_16b_f32 instead of a padded 16x16x4 tile (M = 36 = 2 tiles + 1 group: 72 instead of 96 MFMA
+//   cycles per tap).  Its 16 blocks are (k-slot j) x (4 lanes): lane l feeds its own window element as B and
+//   A[32 + (l&3)][k = j], so block l>>2 accumulates the k = j (mod 4) share of 4 rows x the lane's own pixels;
+//   the four j-shares are added across lanes (xor 16, 32) once per tile, and lane j stores row 32 + j.
 //   Weights (A operand) are staged per 16-channel chunk in LDS as [ci][tap][co] with a leading
 //   dimension == 16 (mod 32): conflict-free ds_read_b32.
 #include "common.h"
@@ -70,11 +75,16 @@ __device__ __forceinline__ Win6 load_win(const float* __restrict__ plane, int yy
 
 // LOGX: log2 of the lanes (x 4 pixels) a 16-lane group spends on x; the other 16>>LOGX lanes take
 // further rows, so narrow images (W = 75, 150) do not waste most of a 64-pixel-wide tile.
-template <int MT, int LOGX>
+constexpr int c3_lda(int mb) { return ((mb + 15) / 32) * 32 + 16; }   // smallest >= mb that is 16 (mod 32)
+
+__device__ __forceinline__ float pick4(f32x4 v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+
+template <int MT, int LEFT, int LOGX>
 __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   extern __shared__ float As[];                 // [kKC][9][ldA]
-  constexpr int MB = 16 * MT;
-  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  constexpr int MB = 16 * MT + 4 * LEFT;        // output channels of one block
+  constexpr int ldA = c3_lda(MB);
+  constexpr int LG = LEFT > 0 ? LEFT : 1;       // array extent (LEFT = 0: unused)
   constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
   constexpr int TROWS = 4 * NY * kR;            // output rows of one block tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,12 +135,18 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
     const bool wave_live = ywave < H;
 
     f32x4 acc[kR][MT][4];
+    f32x4 accl[kR][LG][4];
 #pragma unroll
-    for (int r = 0; r < kR; ++r)
+    for (int r = 0; r < kR; ++r) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[r][mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int lg = 0; lg < LG; ++lg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accl[r][lg][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kc0 = 0; kc0 < a.K; kc0 += kKC) {
       const int kcn = min(kKC, a.K - kc0);
@@ -162,6 +178,14 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[(((a.dbg & 4) ? 0 : g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
+        float al[9][LG];
+        if (LEFT > 0) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int lg = 0; lg < LEFT; ++lg)
+              al[t][lg] = As[(((a.dbg & 4) ? 0 : g * 4 + j) * 9 + t) * ldA + MT * 16 + lg * 4 + (lane & 3)];
+        }
 #pragma unroll
         for (int iy = 0; iy < kR + 2; ++iy)
 #pragma unroll
@@ -169,16 +193,39 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
             const int dy = iy - r;
             if (dy < 0 || dy > 2) continue;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
+            for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                   acc[r][mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dy * 3 + dx][mt], win[iy].v[e + dx], acc[r][mt][e], 0, 0, 0);
+              if (LEFT > 0) {
+#pragma unroll
+                for (int lg = 0; lg < LEFT; ++lg)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    accl[r][lg][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(al[dy * 3 + dx][lg], win[iy].v[e + dx], accl[r][lg][e], 0, 0, 0);
+              }
+            }
           }
       }
     }
 
+    if (LEFT > 0 && wave_live) {                  // add the four k-slot shares of the 4-row groups (all lanes take part)
+#pragma unroll
+      for (int r = 0; r < kR; ++r)
+#pragma unroll
+        for (int lg = 0; lg < LEFT; ++lg)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float v = accl[r][lg][e][q];
+              v += __shfl_xor(v, 16);
+              v += __shfl_xor(v, 32);
+              accl[r][lg][e][q] = v;
+            }
+    }
     if (x0 >= W || !wave_live) continue;
     if (a.dbg & 1) {
 #pragma unroll
@@ -187,6 +234,12 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[r][mt][e]));
+#pragma unroll
+      for (int r = 0; r < kR; ++r)
+#pragma unroll
+        for (int lg = 0; lg < LEFT; ++lg)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(accl[r][lg][e]));
       continue;
     }
 #pragma unroll
@@ -209,14 +262,28 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
               if (x0 + e < W) row[x0 + e] = v[e];
           }
         }
+#pragma unroll
+      for (int lg = 0; lg < LEFT; ++lg) {          // lane (c, j) stores row 16*MT + 4*lg + j of the 4-row group
+        const int m = m0 + MT * 16 + lg * 4 + j;
+        if (m >= a.M) continue;
+        float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
+        const f32x4 v = {pick4(accl[r][lg][0], j), pick4(accl[r][lg][1], j), pick4(accl[r][lg][2], j), pick4(accl[r][lg][3], j)};
+        if (x0 + 3 < W) {
+          store4u(row + x0, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (x0 + e < W) row[x0 + e] = v[e];
+        }
+      }
     }
   }
 }
 
-template <int MT, int LOGX>
+template <int MT, int LEFT, int LOGX>
 int launch_c3x(C3Args a, int B, hipStream_t s) {
-  constexpr int MB = 16 * MT;
-  constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
+  constexpr int MB = 16 * MT + 4 * LEFT;
+  constexpr int ldA = c3_lda(MB);
   constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
   const int kc = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
   const size_t lds = (size_t)kc * 9 * ldA * sizeof(float);
@@ -229,12 +296,12 @@ int launch_c3x(C3Args a, int B, hipStream_t s) {
   }
   a.tpb = (int)tpb;
   dim3 grid((unsigned)xt, (unsigned)((ntiles + tpb - 1) / tpb), (unsigned)(B * a.nmb));
-  hipLaunchKernelGGL((conv3_kernel<MT, LOGX>), grid, dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((conv3_kernel<MT, LEFT, LOGX>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
-template <int MT>
+template <int MT, int LEFT>
 int launch_c3(const C3Args& a, int B, hipStream_t s) {
   // pick the x extent of a lane group (64 / 32 / 16 pixels) that wastes the fewest columns
   int best = 4;
@@ -244,9 +311,9 @@ int launch_c3(const C3Args& a, int B, hipStream_t s) {
     const long cols = (long)((a.W + tw - 1) / tw) * tw;
     if (cols < best_cols) { best_cols = cols; best = lx; }
   }
-  if (best == 4) return launch_c3x<MT, 4>(a, B, s);
-  if (best == 3) return launch_c3x<MT, 3>(a, B, s);
-  return launch_c3x<MT, 2>(a, B, s);
+  if (best == 4) return launch_c3x<MT, LEFT, 4>(a, B, s);
+  if (best == 3) return launch_c3x<MT, LEFT, 3>(a, B, s);
+  return launch_c3x<MT, LEFT, 2>(a, B, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -477,15 +544,21 @@ int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w
   a.M = M; a.K = K; a.H = H; a.W = W; a.flip = flip; a.replicate = replicate; a.dbg = g_c3_dbg;
   if (c3_thin_applies(M, K) && !(g_c3_dbg & 8))
     return c3_thin_conv(X, x_bs, Wt, w_ms, w_ks, flip, replicate, Y, y_bs, B, M, K, H, W, (hipStream_t)stream);
-  const int T = (M + 15) / 16;
-  const int nblk = (T + 2) / 3;
-  const int MT = (T + nblk - 1) / nblk;
-  a.nmb = (T + MT - 1) / MT;
+  // split M into equal blocks of at most 48 rows; a block is MT 16-row tiles plus LEFT 4-row groups
+  // (MT + LEFT <= 3 accumulator sets), e.g. 36 = 2 tiles + 1 group, 72 = 2 x 36, 144 = 3 x 48, 24 = 1 tile + 2 groups
+  const int nblk = (M + 47) / 48;
+  const int rows = (((M + nblk - 1) / nblk) + 3) & ~3;
+  int MT = rows / 16, LEFT = (rows % 16) / 4;
+  if (MT == 0 || MT + LEFT > 3 || (g_c3_dbg & 16)) { MT = (rows + 15) / 16; LEFT = 0; }
+  a.nmb = (M + 16 * MT + 4 * LEFT - 1) / (16 * MT + 4 * LEFT);
   hipStream_t s = (hipStream_t)stream;
-  switch (MT) {
-    case 1: return launch_c3<1>(a, B, s);
-    case 2: return launch_c3<2>(a, B, s);
-    default: return launch_c3<3>(a, B, s);
+  switch (MT * 4 + LEFT) {
+    case 4: return launch_c3<1, 0>(a, B, s);
+    case 5: return launch_c3<1, 1>(a, B, s);
+    case 6: return launch_c3<1, 2>(a, B, s);
+    case 8: return launch_c3<2, 0>(a, B, s);
+    case 9: return launch_c3<2, 1>(a, B, s);
+    default: return launch_c3<3, 0>(a, B, s);
   }
 }
 

@@ -19,6 +19,6 @@ def run(B, M, K, H, W, flags, iters=10):
     us = e0.elapsed_time(e1) * 1e3 / iters
     return us, 2.0 * 9 * M * K * H * W * B / (us * 1e-6) / 1e12
 
-for sh in [(8, 36, 36, 400, 600), (8, 36, 36, 200, 300), (8, 72, 36, 200, 300), (8, 144, 72, 100, 150), (8, 72, 144, 100, 150), (8, 72, 144, 50, 75), (8, 36, 3, 400, 600), (8, 2, 36, 400, 600)]:
-    r = {f: run(*sh, flags=f) for f in (0, 1, 2, 3, 4, 7)}
-    print(f"{sh}: full {r[0][0]:7.1f} us {r[0][1]:5.1f} TF | no-store {r[1][0]:7.1f} | no-load {r[2][0]:7.1f} | neither {r[3][0]:7.1f} | const-w {r[4][0]:7.1f} | mfma-only {r[7][0]:7.1f} ({r[7][1]:.1f} TF)")
+for sh in [(8, 36, 36, 400, 600), (8, 36, 36, 200, 300), (8, 72, 36, 200, 300), (8, 36, 72, 200, 300), (8, 144, 72, 100, 150), (8, 72, 144, 100, 150), (8, 72, 144, 50, 75)]:
+    r = {f: run(*sh, flags=f) for f in (0, 1, 2, 3, 4, 7, 16)}
+    print(f"{sh}: full {r[0][0]:7.1f} us {r[0][1]:5.1f} TF | no-store {r[1][0]:7.1f} | no-load {r[2][0]:7.1f} | neither {r[3][0]:7.1f} | const-w {r[4][0]:7.1f} | mfma-only {r[7][0]:7.1f} ({r[7][1]:.1f} TF) | padded-tiles {r[16][0]:7.1f}")
