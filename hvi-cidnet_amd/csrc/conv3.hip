@@ -330,135 +330,228 @@ struct C3WgArgs {
   int replicate;
   int rr;           // rows per chunk
   int nseg4;        // ceil(nseg / 4): x-segment groups
-  int nnt;          // number of 16-wide n tiles
+  int nfull, ngrp;  // 16-wide n tiles, 4-wide groups of the input-channel remainder
+  int nby;          // (m block, n block) pairs per pixel chunk in this launch
+  int nchunk;       // pixel chunks per sample
+  int dbg;          // timing-study switches: 32 no main loop, 64 no epilogue
 };
 
 struct Win10 {
   float v[10];
 };
 
-__device__ __forceinline__ Win10 load_win10(const float* __restrict__ plane, int yy, int xs, int H, int W, bool ok,
-                                            bool replicate) {
-  Win10 r;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) r.v[i] = 0.f;
-  if (yy < 0 || yy >= H) {
-    if (replicate) yy = yy < 0 ? 0 : H - 1; else ok = false;
-  }
-  if (!ok) return r;
-  const float* row = plane + (long)yy * W;
-  if (xs >= 1 && xs + 8 < W) {
-    const f32x4 a = load4u(row + xs), b = load4u(row + xs + 4);
-    r.v[0] = row[xs - 1];
-    r.v[1] = a[0]; r.v[2] = a[1]; r.v[3] = a[2]; r.v[4] = a[3];
-    r.v[5] = b[0]; r.v[6] = b[1]; r.v[7] = b[2]; r.v[8] = b[3];
-    r.v[9] = row[xs + 8];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      int x = xs - 1 + i;
-      if (x < 0) { if (replicate) x = 0; else continue; }
-      if (x >= W) { if (replicate) x = W - 1; else continue; }
-      r.v[i] = row[x];
-    }
-  }
+// Window xq-1 .. xq+8 of row yy in two steps, both straight-line code (W >= 8, 0 <= xq <= W-8).  raw_win10 only
+// ISSUES the loads: two 16 B loads that are always inside the row and the two halo scalars at clamped addresses
+// (which is the replicate value).  finish_win10 applies the border selects (zero padding, rows outside the image).
+// The split matters: the loads for row y+1 are issued before row y's MFMA burst and finished after it, so their
+// latency hides behind ~5000 MFMA cycles.  Any arithmetic on the loaded values placed next to the loads (selects,
+// or the joins of a branchy per-element border path) makes the compiler wait for the data BEFORE the burst.
+struct RawWin10 {
+  f32x4 a, b;
+  float lft, rgt;
+};
+
+__device__ __forceinline__ RawWin10 raw_win10(const float* __restrict__ plane, int yy, int xq, int H, int W) {
+  const float* row = plane + (long)min(max(yy, 0), H - 1) * W;
+  RawWin10 r;
+  r.a = load4u(row + xq);
+  r.b = load4u(row + xq + 4);
+  r.lft = row[max(xq - 1, 0)];
+  r.rgt = row[min(xq + 8, W - 1)];
   return r;
 }
 
-template <int MT>
+__device__ __forceinline__ Win10 finish_win10(const RawWin10& w, int yy, int xq, int H, int W, bool replicate) {
+  Win10 r;
+  r.v[0] = (xq == 0 && !replicate) ? 0.f : w.lft;
+  r.v[1] = w.a[0]; r.v[2] = w.a[1]; r.v[3] = w.a[2]; r.v[4] = w.a[3];
+  r.v[5] = w.b[0]; r.v[6] = w.b[1]; r.v[7] = w.b[2]; r.v[8] = w.b[3];
+  r.v[9] = (xq + 8 >= W && !replicate) ? 0.f : w.rgt;
+  const bool ok = replicate || (yy >= 0 && yy < H);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r.v[i] = ok ? r.v[i] : 0.f;
+  return r;
+}
+
+// Fallback for images narrower than 8 pixels (bottom levels of toy-sized inputs): one thread per weight element.
+__global__ void conv3_wgrad_narrow_kernel(const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs,
+                                          int replicate, float* __restrict__ dW, int B, int M, int N, int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N * 9) return;
+  const int m = i / (N * 9), rem = i - m * (N * 9), n = rem / 9, t = rem - n * 9;
+  const int dy = t / 3 - 1, dx = t % 3 - 1;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* g = dY + b * dy_bs + (long)m * H * W;
+    const float* x = X + b * x_bs + (long)n * H * W;
+    for (int y = 0; y < H; ++y)
+      for (int xx = 0; xx < W; ++xx) {
+        int yy = y + dy, xc = xx + dx;
+        if (replicate) { yy = min(max(yy, 0), H - 1); xc = min(max(xc, 0), W - 1); }
+        else if (yy < 0 || yy >= H || xc < 0 || xc >= W) continue;
+        s += g[(long)y * W + xx] * x[(long)yy * W + xc];
+      }
+  }
+  dW[i] = s;
+}
+
+// MT 16-row tiles + LEFT 4-row groups of output channels per block (as in the forward kernel).  NLEFT = false: the
+// block owns a full 16-column n tile (16x16x4 MFMAs for the tiles, 4x4x1 for the row groups).  NLEFT = true: the
+// block owns one 4-column group of the input-channel remainder (N = 36: columns 32..35) and runs everything on
+// 4x4x1: its 16 blocks are (k-slot j) x (4 row- or column-groups), lane l feeding its own dY / X values, so no
+// operand is padded to 16.  4x4x1 results hold one k-slot's share per 16-lane group; the shares are added in the
+// LDS pass that also adds the four waves.
+template <int MT, int LEFT, bool NLEFT>
 __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
-  extern __shared__ float red[];                 // [4 waves][MT*4][64]
+  extern __shared__ float red[];                 // [4 waves][(MT+LEFT)*4][64]
+  constexpr int LG = LEFT > 0 ? LEFT : 1;
+  constexpr int MB = 16 * MT + 4 * LEFT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, j = lane >> 4;
   const int b = blockIdx.z;
-  const int mb = blockIdx.y / a.nnt, nt = blockIdx.y - mb * a.nnt;
-  const int m0 = mb * 16 * MT, n0 = nt * 16;
-  const int segg = blockIdx.x % a.nseg4, rchunk = blockIdx.x / a.nseg4;
+  const int chunk = blockIdx.x, by = blockIdx.y;
+  const int nny = NLEFT ? a.ngrp : a.nfull;       // n blocks of this launch
+  const int mb = by / nny, nt = by - mb * nny;
+  const int m0 = mb * MB, n0 = NLEFT ? a.nfull * 16 + nt * 4 : nt * 16;
+  const int segg = chunk % a.nseg4, rchunk = chunk / a.nseg4;
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
   const int xs = ((segg * 4 + wave) * 32) + 8 * j;         // this lane's first pixel of the segment
   const bool seg_ok = (segg * 4 + wave) * 32 < W;
+  // the lane that crosses the right border is pulled back to W-8 and its first `dup` pixels (owned by its left
+  // neighbour) are masked out of the A operand; lanes entirely past the border mask everything (W >= 8)
+  const int xq = min(xs, W - 8), dup = xs - xq;
   const int ya = rchunk * a.rr, yb = min(ya + a.rr, H);
   const bool rep = a.replicate != 0;
 
   f32x4 acc[9][MT];
+  f32x4 accl[9][LG];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 9; ++t) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int lg = 0; lg < LG; ++lg) accl[t][lg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  if (seg_ok && ya < yb) {
+  if (seg_ok && ya < yb && !(a.dbg & 32)) {
     // rows / columns past M / N are clamped to a valid plane: they only reach accumulator entries
     // that are never stored
-    const float* xpl = a.X + (long)b * a.x_bs + (long)min(n0 + r, a.N - 1) * HW;
-    const float* ypl[MT];
+    const float* xpl = a.X + (long)b * a.x_bs + (long)min(n0 + (NLEFT ? (lane & 3) : r), a.N - 1) * HW;
+    const float* ypl[MT + LG];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) ypl[mt] = a.dY + (long)b * a.dy_bs + (long)min(m0 + mt * 16 + r, a.M - 1) * HW;
-    auto load_dy = [&](int y, float (&av)[MT][8]) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+    for (int lg = 0; lg < LG; ++lg)
+      ypl[MT + lg] = a.dY + (long)b * a.dy_bs + (long)min(m0 + MT * 16 + lg * 4 + (lane & 3), a.M - 1) * HW;
+    f32x4 dyraw[MT + LG][2];                       // next row's dY, as loaded
+    auto issue_dy = [&](int y) {
+#pragma unroll
+      for (int mt = 0; mt < MT + LEFT; ++mt) {
         const float* row = ypl[mt] + (long)y * W;
-        if (xs + 7 < W) {
-          const f32x4 p = load4u(row + xs), q = load4u(row + xs + 4);
-          av[mt][0] = p[0]; av[mt][1] = p[1]; av[mt][2] = p[2]; av[mt][3] = p[3];
-          av[mt][4] = q[0]; av[mt][5] = q[1]; av[mt][6] = q[2]; av[mt][7] = q[3];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) av[mt][e] = (xs + e < W) ? row[xs + e] : 0.f;
-        }
+        dyraw[mt][0] = load4u(row + xq);
+        dyraw[mt][1] = load4u(row + xq + 4);
       }
     };
-    Win10 w0 = load_win10(xpl, ya - 1, xs, H, W, true, rep);
-    Win10 w1 = load_win10(xpl, ya, xs, H, W, true, rep);
-    Win10 w2n = load_win10(xpl, ya + 1, xs, H, W, true, rep);
-    float avn[MT][8];
-    load_dy(ya, avn);
+    Win10 w0 = finish_win10(raw_win10(xpl, ya - 1, xq, H, W), ya - 1, xq, H, W, rep);
+    Win10 w1 = finish_win10(raw_win10(xpl, ya, xq, H, W), ya, xq, H, W, rep);
+    RawWin10 w2raw = raw_win10(xpl, ya + 1, xq, H, W);
+    issue_dy(ya);
     for (int y = ya; y < yb; ++y) {
-      const Win10 w2 = w2n;
-      float av[MT][8];
+      // consume what was requested one iteration (one MFMA burst) ago ...
+      const Win10 w2 = finish_win10(w2raw, y + 1, xq, H, W, rep);
+      float av[MT + LG][8];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT + LEFT; ++mt)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) av[mt][e] = avn[mt][e];
-      if (y + 1 < yb) {                           // prefetch the next row's operands
-        w2n = load_win10(xpl, y + 2, xs, H, W, true, rep);
-        load_dy(y + 1, avn);
+        for (int e = 0; e < 8; ++e) av[mt][e] = e < dup ? 0.f : dyraw[mt][e >> 2][e & 3];
+      // ... and request the next row's operands before this row's burst
+      if (y + 1 < yb) {
+        w2raw = raw_win10(xpl, y + 2, xq, H, W);
+        issue_dy(y + 1);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+        for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            acc[dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w0.v[e + dx], acc[dx][mt], 0, 0, 0);
-            acc[3 + dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w1.v[e + dx], acc[3 + dx][mt], 0, 0, 0);
-            acc[6 + dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w2.v[e + dx], acc[6 + dx][mt], 0, 0, 0);
+            if (NLEFT) {
+              acc[dx][mt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[mt][e], w0.v[e + dx], acc[dx][mt], 0, 0, 0);
+              acc[3 + dx][mt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[mt][e], w1.v[e + dx], acc[3 + dx][mt], 0, 0, 0);
+              acc[6 + dx][mt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[mt][e], w2.v[e + dx], acc[6 + dx][mt], 0, 0, 0);
+            } else {
+              acc[dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w0.v[e + dx], acc[dx][mt], 0, 0, 0);
+              acc[3 + dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w1.v[e + dx], acc[3 + dx][mt], 0, 0, 0);
+              acc[6 + dx][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w2.v[e + dx], acc[6 + dx][mt], 0, 0, 0);
+            }
           }
+#pragma unroll
+          for (int lg = 0; lg < LEFT; ++lg) {
+            accl[dx][lg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MT + lg][e], w0.v[e + dx], accl[dx][lg], 0, 0, 0);
+            accl[3 + dx][lg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MT + lg][e], w1.v[e + dx], accl[3 + dx][lg], 0, 0, 0);
+            accl[6 + dx][lg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MT + lg][e], w2.v[e + dx], accl[6 + dx][lg], 0, 0, 0);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
       w0 = w1; w1 = w2;
     }
   }
 
-  // sum the four waves' tiles through LDS (one tap per round), one slab per block
-  float* slab = a.slabs + (((long)b * gridDim.x + blockIdx.x) * (long)a.M) * a.N * 9;
-  constexpr int TILE = MT * 4;
+  // sum the four waves' tiles (and, for 4x4x1 results, the four k-slot shares) through LDS, one tap per round
+  float* slab = a.slabs + (((long)b * a.nchunk + chunk) * (long)a.M) * a.N * 9;
+  constexpr int TILE = (MT + LEFT) * 4;
+  if (a.dbg & 64) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(acc[t][mt]));
+#pragma unroll
+      for (int lg = 0; lg < LEFT; ++lg) asm volatile("" ::"v"(accl[t][lg]));
+    }
+    return;
+  }
   for (int t = 0; t < 9; ++t) {
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT + LEFT; ++mt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         float v = 0.f;
 #pragma unroll
-        for (int tt = 0; tt < 9; ++tt) v = (tt == t) ? acc[tt][mt][reg] : v;    // static register indexing
+        for (int tt = 0; tt < 9; ++tt) {                                   // static register indexing
+          if (mt < MT) v = (tt == t) ? acc[tt][mt < MT ? mt : 0][reg] : v;
+          else v = (tt == t) ? accl[tt][mt >= MT ? mt - MT : 0][reg] : v;
+        }
         red[(wave * TILE + mt * 4 + reg) * 64 + lane] = v;
       }
     __syncthreads();
     for (int idx = threadIdx.x; idx < TILE * 64; idx += kThreads) {
-      const float v = (red[idx] + red[TILE * 64 + idx]) + (red[2 * TILE * 64 + idx] + red[3 * TILE * 64 + idx]);
       const int l = idx & 63, q = idx >> 6;
       const int reg = q & 3, mt = q >> 2;
-      const int m = m0 + mt * 16 + (l >> 4) * 4 + reg, n = n0 + (l & 15);
-      if (m < a.M && n < a.N) slab[((long)m * a.N + n) * 9 + t] = v;
+      const bool x4 = NLEFT || mt >= MT;                                   // produced by 4x4x1: k-slot shares in l, l+16, l+32, l+48
+      if (x4 && l >= 16) continue;
+      float v = 0.f;
+      if (x4) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int k = idx + 16 * jj;
+          v += (red[k] + red[TILE * 64 + k]) + (red[2 * TILE * 64 + k] + red[3 * TILE * 64 + k]);
+        }
+      } else {
+        v = (red[idx] + red[TILE * 64 + idx]) + (red[2 * TILE * 64 + idx] + red[3 * TILE * 64 + idx]);
+      }
+      int m, n;
+      if (!NLEFT) {
+        m = m0 + (mt < MT ? mt * 16 + (l >> 4) * 4 + reg : MT * 16 + (mt - MT) * 4 + reg);
+        n = n0 + (l & 15);
+      } else {
+        if (mt >= MT && l >= 4) continue;                                  // the 4 row-group blocks hold identical values
+        m = m0 + (mt < MT ? mt * 16 + 4 * (l >> 2) + reg : MT * 16 + (mt - MT) * 4 + reg);
+        n = n0 + (l & 3);
+      }
+      if (m < a.M && m < m0 + MB && n < a.N) slab[((long)m * a.N + n) * 9 + t] = v;
     }
   }
 }
@@ -476,16 +569,41 @@ __global__ __launch_bounds__(256) void c3_reduce_kernel(const float* __restrict_
     out[i] = ((part[0][ex] + part[1][ex]) + (part[2][ex] + part[3][ex])) + ((part[4][ex] + part[5][ex]) + (part[6][ex] + part[7][ex]));
 }
 
-// rows per chunk: enough blocks to fill the chip (>= ~1024) without going below 16 rows per block
+// Decomposition of the (M x N) weight-gradient into blocks.  Output channels: equal blocks of <= 48 rows = MT 16-row
+// tiles + LEFT 4-row groups (MT + LEFT <= 3 accumulator sets; see cidnet_conv3x3).  Input channels: full 16-column
+// tiles, and a remainder of <= 8 columns as 4-column groups run by the NLEFT kernel (else one more padded tile).
+struct WgSplit {
+  int MT, LEFT, nmb, nfull, ngrp;
+};
+
+inline WgSplit wg_split(int M, int N) {
+  WgSplit w;
+  const int nblk = (M + 47) / 48;
+  const int rows = (((M + nblk - 1) / nblk) + 3) & ~3;
+  w.MT = rows / 16; w.LEFT = (rows % 16) / 4;
+  if (w.MT == 0 || w.MT + w.LEFT > 3 || (g_c3_dbg & 16)) { w.MT = (rows + 15) / 16; w.LEFT = 0; }
+  w.nmb = (M + 16 * w.MT + 4 * w.LEFT - 1) / (16 * w.MT + 4 * w.LEFT);
+  w.nfull = N / 16; w.ngrp = ((N % 16) + 3) / 4;
+  if (w.nfull == 0 || w.ngrp > 2 || (g_c3_dbg & 16)) { w.nfull = (N + 15) / 16; w.ngrp = 0; }
+  return w;
+}
+
+// Rows per pixel chunk.  256 CUs hold 512 of these blocks at a time (2 waves per SIMD), and a block's run time is
+// (rows + ~6 rows' worth of prologue / 9-round epilogue), so the launch costs about ceil(blocks / 512) * (rows + 6):
+// a grid just above a multiple of 512 pays a whole extra round for a few blocks.  Pick the cheapest row count >= 8.
 inline int wg_rows(int B, int M, int N, int H, int W) {
-  const int T = (M + 15) / 16;
-  const int nblk = (T + 2) / 3;
-  const int MT = (T + nblk - 1) / nblk;
-  const int per_chunk = (((W + 31) / 32 + 3) / 4) * ((T + MT - 1) / MT) * ((N + 15) / 16) * B;
-  int nrc = (1024 + per_chunk - 1) / per_chunk;
-  const int max_nrc = H / 16 > 0 ? H / 16 : 1;
-  nrc = nrc < 1 ? 1 : (nrc > max_nrc ? max_nrc : nrc);
-  return (H + nrc - 1) / nrc;
+  const WgSplit w = wg_split(M, N);
+  const long per_rc = (long)(((W + 31) / 32 + 3) / 4) * w.nmb * w.nfull * B;     // blocks of the main launch per row chunk
+  int best_rr = H;
+  long best_cost = -1;
+  for (int nrc = 1; nrc <= H; ++nrc) {
+    const int rr = (H + nrc - 1) / nrc;
+    if (rr < 8 && nrc > 1) break;
+    const long rounds = (per_rc * ((H + rr - 1) / rr) + 511) / 512;
+    const long cost = rounds * (rr + 6);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rr = rr; }
+  }
+  return best_rr;
 }
 
 // Border correction of the data gradient of (ReplicationPad2d(1) + valid 3x3 conv): the zero-pad
@@ -582,23 +700,47 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
     CIDNET_LAUNCH_STATUS();
     return CIDNET_OK;
   }
+  if (W < 8) {
+    hipLaunchKernelGGL(conv3_wgrad_narrow_kernel, dim3((unsigned)((M * N * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dY,
+                       dy_bs, X, x_bs, replicate, dW, B, M, N, H, W);
+    CIDNET_LAUNCH_STATUS();
+    return CIDNET_OK;
+  }
   C3WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.H = H; a.W = W;
   a.replicate = replicate; a.rr = wg_rows(B, M, N, H, W);
   a.nseg4 = ((W + 31) / 32 + 3) / 4;
-  a.nnt = (N + 15) / 16;
   const int chunks = a.nseg4 * ((H + a.rr - 1) / a.rr);
-  const int T = (M + 15) / 16;
-  const int nblk = (T + 2) / 3;
-  const int MT = (T + nblk - 1) / nblk;
-  const int nmb = (T + MT - 1) / MT;
-  dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnt), (unsigned)B);
+  const WgSplit sp = wg_split(M, N);
+  const int MT = sp.MT, LEFT = sp.LEFT, nmb = sp.nmb, nfull = sp.nfull, ngrp = sp.ngrp;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)4 * MT * 4 * 64 * sizeof(float);
-  if (MT == 1) hipLaunchKernelGGL((conv3_wgrad_kernel<1>), grid, dim3(kThreads), lds, s, a);
-  else if (MT == 2) hipLaunchKernelGGL((conv3_wgrad_kernel<2>), grid, dim3(kThreads), lds, s, a);
-  else hipLaunchKernelGGL((conv3_wgrad_kernel<3>), grid, dim3(kThreads), lds, s, a);
-  CIDNET_LAUNCH_STATUS();
+  const size_t lds = (size_t)4 * (MT + LEFT) * 4 * 64 * sizeof(float);
+  a.nfull = nfull; a.ngrp = ngrp; a.nchunk = chunks; a.dbg = g_c3_dbg;
+  const int code = MT * 4 + LEFT;
+#define CIDNET_WG_LAUNCH(MT_, LEFT_, NL_) hipLaunchKernelGGL((conv3_wgrad_kernel<MT_, LEFT_, NL_>), grid, dim3(kThreads), lds, s, a)
+#define CIDNET_WG_DISPATCH(NL_)                                                  \
+  switch (code) {                                                                \
+    case 4: CIDNET_WG_LAUNCH(1, 0, NL_); break;                                  \
+    case 5: CIDNET_WG_LAUNCH(1, 1, NL_); break;                                  \
+    case 6: CIDNET_WG_LAUNCH(1, 2, NL_); break;                                  \
+    case 8: CIDNET_WG_LAUNCH(2, 0, NL_); break;                                  \
+    case 9: CIDNET_WG_LAUNCH(2, 1, NL_); break;                                  \
+    default: CIDNET_WG_LAUNCH(3, 0, NL_); break;                                 \
+  }
+  {
+    a.nby = nmb * nfull;
+    const dim3 grid((unsigned)chunks, (unsigned)a.nby, (unsigned)B);
+    CIDNET_WG_DISPATCH(false)
+    CIDNET_LAUNCH_STATUS();
+  }
+  if (ngrp > 0) {
+    a.nby = nmb * ngrp;
+    const dim3 grid((unsigned)chunks, (unsigned)a.nby, (unsigned)B);
+    CIDNET_WG_DISPATCH(true)
+    CIDNET_LAUNCH_STATUS();
+  }
+#undef CIDNET_WG_DISPATCH
+#undef CIDNET_WG_LAUNCH
   const long ne = (long)M * N * 9;
   hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, s, ws, B * chunks, ne, dW);
   CIDNET_LAUNCH_STATUS();
