@@ -73,13 +73,45 @@ __device__ __forceinline__ Win6 load_win(const float* __restrict__ plane, int yy
   return r;
 }
 
+// Straight-line window loads for W >= 8 in two steps (see the weight-gradient kernel below for why): raw_win only
+// ISSUES the loads, at addresses clamped into the row; finish_win rebuilds the window of a border lane with selects.
+// A lane whose 4 pixels cross the right border is pulled back to W-4 (it recomputes pixels its neighbour also owns
+// and stores identical values), so every lane loads and stores whole vectors.
+struct RawWin6 {
+  f4u a;
+  f2u b;
+};
+
+__device__ __forceinline__ RawWin6 raw_win(const float* __restrict__ plane, int yy, int xq, int H, int W) {
+  const float* row = plane + (long)min(max(yy, 0), H - 1) * W;
+  RawWin6 r;
+  r.a = *reinterpret_cast<const f4u*>(row + max(xq - 1, 0));
+  r.b = *reinterpret_cast<const f2u*>(row + min(xq + 3, W - 2));
+  return r;
+}
+
+__device__ __forceinline__ Win6 finish_win(const RawWin6& w, int yy, int xq, int H, int W, bool replicate) {
+  const bool left = xq == 0, right = xq + 4 >= W;
+  Win6 r;
+  r.v[0] = left ? (replicate ? w.a.x : 0.f) : w.a.x;
+  r.v[1] = left ? w.a.x : w.a.y;
+  r.v[2] = left ? w.a.y : w.a.z;
+  r.v[3] = left ? w.a.z : w.a.w;
+  r.v[4] = right ? w.b.y : w.b.x;
+  r.v[5] = right ? (replicate ? w.b.y : 0.f) : w.b.y;
+  const bool ok = replicate || (yy >= 0 && yy < H);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = ok ? r.v[i] : 0.f;
+  return r;
+}
+
 // LOGX: log2 of the lanes (x 4 pixels) a 16-lane group spends on x; the other 16>>LOGX lanes take
 // further rows, so narrow images (W = 75, 150) do not waste most of a 64-pixel-wide tile.
 constexpr int c3_lda(int mb) { return ((mb + 15) / 32) * 32 + 16; }   // smallest >= mb that is 16 (mod 32)
 
 __device__ __forceinline__ float pick4(f32x4 v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
 
-template <int MT, int LEFT, int LOGX>
+template <int MT, int LEFT, int LOGX, bool NARROW>
 __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   extern __shared__ float As[];                 // [kKC][9][ldA]
   constexpr int MB = 16 * MT + 4 * LEFT;        // output channels of one block
@@ -93,6 +125,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   const int m0 = mb * MB;
   const int x0 = blockIdx.x * (XL * 4) + 4 * (c & (XL - 1));
   const int H = a.H, W = a.W;
+  const int xq = NARROW ? x0 : min(x0, W - 4);    // NARROW (W < 8): per-element border path, its own instantiation
   const long HW = (long)H * W;
   const float* Xb = a.X + (long)b * a.x_bs;
   const bool rep = a.replicate != 0;
@@ -158,20 +191,27 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
       }
       if (!wave_live) continue;                  // wave-uniform; the wave still joins the barriers above
       // channels past K are clamped to a valid plane: their weights are zero in LDS
-      Win6 nxt[kR + 2];
+      Win6 nxt[kR + 2];                          // NARROW: finished windows of the next k-group
+      RawWin6 raw[kR + 2];                       // otherwise: its loads, as issued
       {
         const float* plane = Xb + (long)min(kc0 + j, a.K - 1) * HW;
 #pragma unroll
-        for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+        for (int iy = 0; iy < kR + 2; ++iy) {
+          if (NARROW) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+          else raw[iy] = raw_win(plane, yw - 1 + iy, xq, H, W);
+        }
       }
       for (int g = 0; g < ng; ++g) {
         Win6 win[kR + 2];
 #pragma unroll
-        for (int iy = 0; iy < kR + 2; ++iy) win[iy] = nxt[iy];
+        for (int iy = 0; iy < kR + 2; ++iy) win[iy] = NARROW ? nxt[iy] : finish_win(raw[iy], yw - 1 + iy, xq, H, W, rep);
         if (g + 1 < ng && !(a.dbg & 2)) {
           const float* plane = Xb + (long)min(kc0 + 4 * (g + 1) + j, a.K - 1) * HW;
 #pragma unroll
-          for (int iy = 0; iy < kR + 2; ++iy) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+          for (int iy = 0; iy < kR + 2; ++iy) {
+            if (NARROW) nxt[iy] = load_win(plane, yw - 1 + iy, x0, H, W, rep);
+            else raw[iy] = raw_win(plane, yw - 1 + iy, xq, H, W);
+          }
         }
         float av[9][MT];
 #pragma unroll
@@ -186,6 +226,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
             for (int lg = 0; lg < LEFT; ++lg)
               al[t][lg] = As[(((a.dbg & 4) ? 0 : g * 4 + j) * 9 + t) * ldA + MT * 16 + lg * 4 + (lane & 3)];
         }
+        if (!NARROW) __builtin_amdgcn_sched_barrier(0);     // keep the next group's loads ahead of this group's MFMA burst
 #pragma unroll
         for (int iy = 0; iy < kR + 2; ++iy)
 #pragma unroll
@@ -254,8 +295,8 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
           if (m >= a.M) continue;
           float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
           const f32x4 v = {acc[r][mt][0][reg], acc[r][mt][1][reg], acc[r][mt][2][reg], acc[r][mt][3][reg]};
-          if (x0 + 3 < W) {
-            store4u(row + x0, v);
+          if (!NARROW) {
+            store4u(row + xq, v);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -268,8 +309,8 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
         if (m >= a.M) continue;
         float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
         const f32x4 v = {pick4(accl[r][lg][0], j), pick4(accl[r][lg][1], j), pick4(accl[r][lg][2], j), pick4(accl[r][lg][3], j)};
-        if (x0 + 3 < W) {
-          store4u(row + x0, v);
+        if (!NARROW) {
+          store4u(row + xq, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -280,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   }
 }
 
-template <int MT, int LEFT, int LOGX>
+template <int MT, int LEFT, int LOGX, bool NARROW>
 int launch_c3x(C3Args a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT + 4 * LEFT;
   constexpr int ldA = c3_lda(MB);
@@ -296,7 +337,7 @@ int launch_c3x(C3Args a, int B, hipStream_t s) {
   }
   a.tpb = (int)tpb;
   dim3 grid((unsigned)xt, (unsigned)((ntiles + tpb - 1) / tpb), (unsigned)(B * a.nmb));
-  hipLaunchKernelGGL((conv3_kernel<MT, LEFT, LOGX>), grid, dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((conv3_kernel<MT, LEFT, LOGX, NARROW>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -311,9 +352,10 @@ int launch_c3(const C3Args& a, int B, hipStream_t s) {
     const long cols = (long)((a.W + tw - 1) / tw) * tw;
     if (cols < best_cols) { best_cols = cols; best = lx; }
   }
-  if (best == 4) return launch_c3x<MT, LEFT, 4>(a, B, s);
-  if (best == 3) return launch_c3x<MT, LEFT, 3>(a, B, s);
-  return launch_c3x<MT, LEFT, 2>(a, B, s);
+  if (a.W < 8) return launch_c3x<MT, LEFT, 2, true>(a, B, s);
+  if (best == 4) return launch_c3x<MT, LEFT, 4, false>(a, B, s);
+  if (best == 3) return launch_c3x<MT, LEFT, 3, false>(a, B, s);
+  return launch_c3x<MT, LEFT, 2, false>(a, B, s);
 }
 
 // ---------------------------------------------------------------------------------------------
