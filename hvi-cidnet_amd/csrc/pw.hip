@@ -23,6 +23,7 @@ constexpr int kThreads = 256;
 constexpr int kDepth = 4;     // k-steps of the activation operand prefetched per wave
 int g_pw_force_mt = 0;          // timing studies: force the channel-tile count per block
 long g_pw_target_blocks = 512;   // blocks a launch aims for (each walks several pixel tiles)
+bool g_pw_target_set = false;    // cidnet_debug_pw_flags overrode it
 int g_pw_dbg = 0;             // timing-study switches (cidnet_debug_pw_flags): 1 no stores, 2 no K loop, 4 LDS kernel only
 
 struct PwArgs {
@@ -344,7 +345,8 @@ template <int MT, int EPI, int KS>
 int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   constexpr int MB = 16 * MT;
   const long mblocks = (a.M + MB - 1) / MB;
-  long tpb = (nstream * mblocks * B + g_pw_target_blocks - 1) / g_pw_target_blocks;
+  const long target = g_pw_target_set ? g_pw_target_blocks : 256;     // fat blocks: the weight fragments are loaded once per block
+  long tpb = (nstream * mblocks * B + target - 1) / target;
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   a.tpb = (int)tpb;
   a.tile0 = 0;
@@ -485,7 +487,9 @@ int splitk_one(const PwArgs& a, int B, hipStream_t s) {
 
 template <int EPI>
 bool try_splitk(const PwArgs& a, int B, hipStream_t s, int* rc) {
-  if (a.HW > 8192 || a.K < 64 || a.K > 768) return false;
+  // planes up to 8192 pixels (too few pixel tiles to fill the chip otherwise), and up to 16384 when K is too deep
+  // for the LDS-resident weight panel (that kernel would re-stage the panel for every pixel tile)
+  if (a.HW > 16384 || (a.HW > 8192 && a.K <= 320) || a.K < 64 || a.K > 768) return false;
   if (a.K <= 384) { *rc = splitk_one<EPI>(a, B, s); return true; }
   PwArgs lo = a, hi = a;
   lo.K = 384;
@@ -560,12 +564,14 @@ int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
   const int ks = (a.K + 3) / 4;
   int MT;
   if (ks <= 24 && !(g_pw_dbg & 4)) {
-    // register-resident weights: at most 4 (ks <= 9) or 3 channel tiles per block; fewest padded tiles wins
+    // register-resident weights: at most 4 (ks <= 9) or 3 channel tiles per block.  Every block of output channels
+    // re-reads the whole input, so take the largest tile count that pads at most one tile in total
+    // (tools/sweep_pw.py: M=72 runs 88 us with 3+2(+1 padded) tiles, 120 us as five single-tile blocks)
     const int mtmax = ks <= 9 ? 4 : 3;
-    int best = 1, best_pad = 1 << 30;
+    int best = 1;
     for (int mt = mtmax; mt >= 1; --mt) {
       const int pad = ((T + mt - 1) / mt) * mt;
-      if (pad < best_pad) { best_pad = pad; best = mt; }
+      if (pad <= T + 1) { best = mt; break; }
     }
     MT = best;
     if (g_pw_force_mt >= 1 && g_pw_force_mt <= mtmax) MT = g_pw_force_mt;
@@ -733,7 +739,8 @@ extern "C" {
 void cidnet_debug_pw_flags(int flags) {
   g_pw_dbg = flags & 0xFF;
   g_pw_force_mt = (flags >> 28) & 7;
-  if ((flags >> 8) & 0xFFFFF) g_pw_target_blocks = (flags >> 8) & 0xFFFFF;
+  g_pw_target_set = ((flags >> 8) & 0xFFFFF) != 0;
+  g_pw_target_blocks = g_pw_target_set ? (flags >> 8) & 0xFFFFF : 512;
 }
 
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,

@@ -27,7 +27,7 @@ def run(B, M, K, HW, flags, iters=20):
     return us, gb / (us * 1e-6) / 1e3, tf / (us * 1e-6)
 
 if __name__ == "__main__":
-    shapes = [(8, 190, 36, 60000), (8, 36, 190, 60000), (8, 36, 36, 60000), (8, 36, 95, 60000), (8, 72, 72, 15000),
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(8, 190, 36, 60000), (8, 36, 190, 60000), (8, 36, 36, 60000), (8, 36, 95, 60000), (8, 72, 72, 15000),
               (8, 382, 72, 15000), (8, 766, 144, 3750), (8, 144, 766, 3750), (8, 36, 36, 240000)]
     for sh in shapes:
         mts = " ".join(f"MT{mt}:{run(*sh, flags=(512 << 8) | (mt << 28))[0]:.1f}" for mt in (1, 2, 3, 4))
