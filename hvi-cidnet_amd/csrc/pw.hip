@@ -345,7 +345,7 @@ template <int MT, int EPI, int KS>
 int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   constexpr int MB = 16 * MT;
   const long mblocks = (a.M + MB - 1) / MB;
-  const long target = g_pw_target_set ? g_pw_target_blocks : 256;     // fat blocks: the weight fragments are loaded once per block
+  const long target = g_pw_target_blocks;
   long tpb = (nstream * mblocks * B + target - 1) / target;
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   a.tpb = (int)tpb;
