@@ -47,20 +47,62 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < TI; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (long p = pbeg + wave * 32; p < pend; p += 128) {
-    const long pl = p + 8 * j;
-    f32x4 qa[TI][2], ka[TI][2];
+  // Straight-line loads: rows past ch are clamped to a valid row (they only reach accumulator entries that are
+  // never stored), and the step that crosses the end of the chunk is pulled back to pend-8 with its first `dup`
+  // pixels (owned by the previous k-slot) masked out of q.  The next step's loads are issued before this step's
+  // MFMAs and consumed one iteration later, so their latency hides behind the burst.
+  const float* qrow[TI];
+  const float* krow[TI];
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    const long row = min(t * 16 + r, ch - 1);
+    qrow[t] = qb + row * HW;
+    krow[t] = kb + row * HW;
+  }
+  const bool wide = pend - pbeg >= 8;              // always, except degenerate planes: then the checked loader
+  f32x4 qn[TI][2], kn[TI][2];
+  auto issue = [&](long p) {
+    const long pl = min(p + 8 * j, pend - 8);
 #pragma unroll
     for (int t = 0; t < TI; ++t) {
-      const int row = t * 16 + r;
-      const bool ok = row < ch;
-      qa[t][0] = ld_px4(qb + (long)row * HW, pl, pend, ok); qa[t][1] = ld_px4(qb + (long)row * HW, pl + 4, pend, ok);
-      ka[t][0] = ld_px4(kb + (long)row * HW, pl, pend, ok); ka[t][1] = ld_px4(kb + (long)row * HW, pl + 4, pend, ok);
+      qn[t][0] = load4u(qrow[t] + pl); qn[t][1] = load4u(qrow[t] + pl + 4);
+      kn[t][0] = load4u(krow[t] + pl); kn[t][1] = load4u(krow[t] + pl + 4);
+    }
+  };
+  long p = pbeg + wave * 32;
+  if (wide && p < pend) issue(p);
+  for (; p < pend; p += 128) {
+    f32x4 qa[TI][2], ka[TI][2];
+    if (wide) {
+      const long pl = p + 8 * j;
+      const int dup = (int)(pl - min(pl, pend - 8));
+#pragma unroll
+      for (int t = 0; t < TI; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool live = h * 4 + e >= dup;
+            qa[t][h][e] = live ? qn[t][h][e] : 0.f;
+            ka[t][h][e] = live ? kn[t][h][e] : 0.f;
+          }
+      if (p + 128 < pend) issue(p + 128);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      const long pl = p + 8 * j;
+#pragma unroll
+      for (int t = 0; t < TI; ++t) {
+        const bool ok = t * 16 + r < ch;
+        qa[t][0] = ld_px4(qrow[t], pl, pend, ok); qa[t][1] = ld_px4(qrow[t], pl + 4, pend, ok);
+        ka[t][0] = ld_px4(krow[t], pl, pend, ok); ka[t][1] = ld_px4(krow[t], pl + 4, pend, ok);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { nq[t] += qa[t][h][e] * qa[t][h][e]; nk[t] += ka[t][h][e] * ka[t][h][e]; }
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
