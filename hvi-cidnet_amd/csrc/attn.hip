@@ -140,17 +140,29 @@ __global__ __launch_bounds__(kThreads) void softmax_fwd_kernel(const float* __re
                                                                float* __restrict__ shat, float* __restrict__ nqo,
                                                                float* __restrict__ nko, float* __restrict__ Mout, int C,
                                                                int heads, int normalize) {
-  extern __shared__ float sm[];          // [ch*ch + 2ch] sums, then attn [ch*ch]
+  extern __shared__ float sm[];          // [ch*ch + 2ch] sums, attn [ch*ch], Wp head slice [C*ch]
   const int ch = C / heads;
   const int head = blockIdx.x, b = blockIdx.y;
   const int ne = ch * ch + 2 * ch;
   float* S = sm;
   float* A = sm + ne;
+  float* Wl = A + ch * ch;               // Wl[co*ch + k] = Wp[co][head*ch + k]
   const float* base = slabs + (((long)b * heads + head) * n_red) * (long)ne;
+  // this block is one of only heads*B: everything below is a chain of global-memory round trips unless the loads
+  // are independent and in flight together, so the slab sum keeps four partial sums per element (fixed order)
   for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    float t = 0.f;
-    for (int k = 0; k < n_red; ++k) t += base[(long)k * ne + i];
-    S[i] = t;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= n_red; k += 4) {
+      t0 += base[(long)k * ne + i]; t1 += base[(long)(k + 1) * ne + i];
+      t2 += base[(long)(k + 2) * ne + i]; t3 += base[(long)(k + 3) * ne + i];
+    }
+    for (; k < n_red; ++k) t0 += base[(long)k * ne + i];
+    S[i] = (t0 + t1) + (t2 + t3);
+  }
+  for (int i = threadIdx.x; i < C * ch; i += blockDim.x) {
+    const int co = i / ch, k = i - co * ch;
+    Wl[i] = Wp[(long)co * C + head * ch + k];
   }
   __syncthreads();
   const float T = temperature[head];
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void softmax_fwd_kernel(const float* __re
   // M_b[co][head*ch + jj] = sum_i Wp[co][head*ch + i] * attn[i][jj]
   for (int i = threadIdx.x; i < C * ch; i += blockDim.x) {
     const int co = i / ch, jj = i - co * ch;
-    const float* wrow = Wp + (long)co * C + head * ch;
+    const float* wrow = Wl + co * ch;
     float t = 0.f;
     for (int k = 0; k < ch; ++k) t += wrow[k] * A[k * ch + jj];
     Mout[((long)b * C + co) * C + head * ch + jj] = t;
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
                                                                const float* __restrict__ temperature, float* __restrict__ dWp_b,
                                                                float* __restrict__ dT_b, float* __restrict__ Wqk, int C,
                                                                int heads, int normalize) {
-  extern __shared__ float sm[];    // A[ch*ch], G[ch*ch] (dattn -> dShat), red[ch], red2[ch]
+  extern __shared__ float sm[];    // A[ch*ch], G[ch*ch] (dattn -> dShat), a[ch], e[ch], Sh[ch*ch], Wl[C*ch], Dl[C*ch]
   __shared__ float red[kThreads / 64];
   const int ch = C / heads;
   const int head = blockIdx.x, b = blockIdx.y;
@@ -203,23 +215,33 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
   float* G = sm + ch * ch;
   float* ai = G + ch * ch;      // a_i
   float* ej = ai + ch;          // e_j
+  float* Sh = ej + ch;          // shat of this (sample, head)
+  float* Wl = Sh + ch * ch;     // Wl[co*ch + i] = Wp[co][hc+i]
+  float* Dl = Wl + C * ch;      // Dl[co*ch + j] = dM[co][hc+j]
   const long ho = ((long)b * heads + head) * ch * ch;
   const float* dMb = dM + (long)b * C * C;
   const float T = temperature[head];
-  for (int i = threadIdx.x; i < ch * ch; i += blockDim.x) A[i] = attn[ho + i];
+  // only heads*B of these blocks exist: stage every operand with independent, coalesced loads first, so the
+  // products below run out of LDS instead of being chains of global-memory round trips
+  for (int i = threadIdx.x; i < ch * ch; i += blockDim.x) { A[i] = attn[ho + i]; Sh[i] = shat[ho + i]; }
+  for (int i = threadIdx.x; i < C * ch; i += blockDim.x) {
+    const int co = i / ch, k = i - co * ch;
+    Wl[i] = Wp[(long)co * C + head * ch + k];
+    Dl[i] = dMb[(long)co * C + head * ch + k];
+  }
   __syncthreads();
   // dattn[i][jj] = sum_co Wp[co][hc+i] * dM[co][hc+jj]
   for (int i = threadIdx.x; i < ch * ch; i += blockDim.x) {
     const int row = i / ch, col = i - row * ch;
     float t = 0.f;
-    for (int co = 0; co < C; ++co) t += Wp[(long)co * C + head * ch + row] * dMb[(long)co * C + head * ch + col];
+    for (int co = 0; co < C; ++co) t += Wl[co * ch + row] * Dl[co * ch + col];
     G[i] = t;
   }
   // dWp_b[co][hc+i] = sum_jj dM[co][hc+jj] * attn[i][jj]
   for (int i = threadIdx.x; i < C * ch; i += blockDim.x) {
     const int co = i / ch, row = i - co * ch;
     float t = 0.f;
-    for (int c = 0; c < ch; ++c) t += dMb[(long)co * C + head * ch + c] * A[row * ch + c];
+    for (int c = 0; c < ch; ++c) t += Dl[co * ch + c] * A[row * ch + c];
     dWp_b[((long)b * C + co) * C + head * ch + row] = t;
   }
   __syncthreads();
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
     for (int c = 0; c < ch; ++c) dot += A[row * ch + c] * G[row * ch + c];
     for (int c = 0; c < ch; ++c) {
       const float dl = A[row * ch + c] * (G[row * ch + c] - dot);
-      dt_acc += dl * shat[ho + row * ch + c];
+      dt_acc += dl * Sh[row * ch + c];
       G[row * ch + c] = T * dl;
     }
   }
@@ -239,8 +261,8 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const float* __re
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * ch; i += blockDim.x) {
     float t = 0.f;
-    if (i < ch) { for (int c = 0; c < ch; ++c) t += G[i * ch + c] * shat[ho + i * ch + c]; ai[i] = t; }
-    else { const int c = i - ch; for (int rr = 0; rr < ch; ++rr) t += G[rr * ch + c] * shat[ho + rr * ch + c]; ej[c] = t; }
+    if (i < ch) { for (int c = 0; c < ch; ++c) t += G[i * ch + c] * Sh[i * ch + c]; ai[i] = t; }
+    else { const int c = i - ch; for (int rr = 0; rr < ch; ++rr) t += G[rr * ch + c] * Sh[rr * ch + c]; ej[c] = t; }
   }
   __syncthreads();
   // rows of the (2C x 2C) map [q;k] -> [dq;dk] owned by this head
@@ -311,7 +333,7 @@ int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp,
   if (ch <= 16) hipLaunchKernelGGL((gram_kernel<1>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
   else hipLaunchKernelGGL((gram_kernel<2>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
   CIDNET_LAUNCH_STATUS();
-  const size_t lds = (size_t)(2 * ch * ch + 2 * ch) * sizeof(float);
+  const size_t lds = (size_t)(2 * ch * ch + 2 * ch + C * ch) * sizeof(float);
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)heads, (unsigned)B), dim3(kThreads), lds, s, ws, chunks * 4,
                      temperature, Wp, attn, shat, nq, nk, M, C, heads, normalize);
   CIDNET_LAUNCH_STATUS();
@@ -324,7 +346,7 @@ int cidnet_attn_bwd(const float* dM, const float* Wp, const float* attn, const f
   CIDNET_CHECK_ARG(dM && Wp && attn && shat && nq && nk && temperature && dWp_b && dT_b && Wqk && B > 0 && C > 0 && heads > 0);
   if (C % heads != 0 || C / heads > 32) return CIDNET_ERR_SHAPE;
   const int ch = C / heads;
-  const size_t lds = (size_t)(2 * ch * ch + 2 * ch) * sizeof(float);
+  const size_t lds = (size_t)(3 * ch * ch + 2 * ch + 2 * C * ch) * sizeof(float);
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)heads, (unsigned)B), dim3(kThreads), lds, (hipStream_t)stream, dM, Wp,
                      attn, shat, nq, nk, temperature, dWp_b, dT_b, Wqk, C, heads, normalize);
   CIDNET_LAUNCH_STATUS();

@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_reg_kernel(const float* __res
 template <int C, int VEC, bool CACHE_G>
 __global__ __launch_bounds__(kThreads) void ln_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ gy, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, float* __restrict__ gx, int B,
-                                                              long HW) {
+                                                              const float* __restrict__ rstd, const float* __restrict__ addend,
+                                                              float* __restrict__ gx, int B, long HW) {
   typedef typename Vec<VEC>::T V;
   const long nq = HW / VEC;
   const long total = (long)B * nq;
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_reg_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const V g = CACHE_G ? gw[c] : Vec<VEC>::ld(gb + (long)c * HW) * w[c];
-      Vec<VEC>::st(gxb + (long)c * HW, rs * (g - s1 - xh[c] * s2));
+      V o = rs * (g - s1 - xh[c] * s2);
+      if (addend) o += Vec<VEC>::ld(addend + b * C * HW + p + (long)c * HW);      // gradient of the residual branch (uniform)
+      Vec<VEC>::st(gxb + (long)c * HW, o);
     }
   }
 }
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float* __restric
 
 __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ gy, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, float* __restrict__ gx, int B, int C,
-                                                          long HW) {
+                                                          const float* __restrict__ rstd, const float* __restrict__ addend,
+                                                          float* __restrict__ gx, int B, int C, long HW) {
   const long nq = (HW + 3) >> 2;
   const long total = (long)B * nq;
   const float invC = 1.0f / (float)C;
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
     float* gxb = gx + b * C * HW;
     for (int c = 0; c < C; ++c) {
       const f32x4 xh = (ld4(xb + (long)c * HW, p, n) - u) * rs;
-      st4(gxb + (long)c * HW, p, n, rs * (ld4(gb + (long)c * HW, p, n) * w[c] - s1 - xh * s2));
+      f32x4 o = rs * (ld4(gb + (long)c * HW, p, n) * w[c] - s1 - xh * s2);
+      if (addend) o += ld4(addend + b * C * HW + (long)c * HW, p, n);
+      st4(gxb + (long)c * HW, p, n, o);
     }
   }
 }
@@ -263,8 +267,9 @@ int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, flo
 
 long cidnet_ln_cf_bwd_ws_floats(int C) { return 2L * 2048 + 4L * C * 64; }
 
-int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd, float* gx,
-                     float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW, void* stream) {
+int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd,
+                         const float* addend, float* gx, float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW,
+                         void* stream) {
   CIDNET_CHECK_ARG(x && weight && gy && mean && rstd && gw && gb && ws && B > 0 && C > 0 && HW > 0);
   const int nchunk = wb_chunks(B, C, HW);
   if (ws_floats < 2L * C * nchunk) return CIDNET_ERR_WS;
@@ -272,16 +277,16 @@ int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const
   if (gx) {
     if (C == 36 && HW % 2 == 0)
       hipLaunchKernelGGL((ln_bwd_reg_kernel<36, 2, true>), dim3(grid_for((long)B * HW / 2)), dim3(kThreads), 0, s, x, weight, gy, mean,
-                         rstd, gx, B, HW);
+                         rstd, addend, gx, B, HW);
     else if (C == 72)
       hipLaunchKernelGGL((ln_bwd_reg_kernel<72, 1, true>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, gy, mean,
-                         rstd, gx, B, HW);
+                         rstd, addend, gx, B, HW);
     else if (C == 144)
       hipLaunchKernelGGL((ln_bwd_reg_kernel<144, 1, false>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, gy,
-                         mean, rstd, gx, B, HW);
+                         mean, rstd, addend, gx, B, HW);
     else
       hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, s, x, weight, gy, mean, rstd,
-                         gx, B, C, HW);
+                         addend, gx, B, C, HW);
     CIDNET_LAUNCH_STATUS();
   }
   hipLaunchKernelGGL(ln_wb_kernel, dim3((unsigned)nchunk, (unsigned)C), dim3(kThreads), 0, s, x, gy, mean, rstd, ws, B, C, HW,
@@ -290,6 +295,11 @@ int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const
   hipLaunchKernelGGL(ln_wb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nchunk, C, gw, gb);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd, float* gx,
+                     float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW, void* stream) {
+  return cidnet_ln_cf_bwd_res(x, weight, gy, mean, rstd, nullptr, gx, gw, gb, ws, ws_floats, B, C, HW, stream);
 }
 
 }  // extern "C"

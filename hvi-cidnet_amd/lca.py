@@ -63,7 +63,8 @@ class HV_LCA(nn.Module):
         self.ffn = CAB(dim, num_heads, bias)
 
     def forward(self, x, y):
-        x = self.ffn(self.norm(x), self.norm(y), residual=x)
+        xn, xr = self.norm.forward_res(x)          # xr is x: the residual's gradient is added inside the LN backward
+        x = self.ffn(xn, self.norm(y), residual=xr)
         return self.gdfn(self.norm(x))
 
 
@@ -77,5 +78,7 @@ class I_LCA(nn.Module):
         self.ffn = CAB(dim, num_heads, bias=bias)
 
     def forward(self, x, y):
-        x = self.ffn(self.norm(x), self.norm(y), residual=x)
-        return self.gdfn(self.norm(x), residual=x)
+        xn, xr = self.norm.forward_res(x)          # xr is x: the residual's gradient is added inside the LN backward
+        x = self.ffn(xn, self.norm(y), residual=xr)
+        xn, xr = self.norm.forward_res(x)
+        return self.gdfn(xn, residual=xr)

@@ -296,6 +296,43 @@ class LayerNormCFFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class LayerNormResFn(torch.autograd.Function):
+    """LayerNorm of a pre-norm residual block (net/LCA.py:79,80,91,92): returns (norm(x), x).  The second output is x
+    itself, to be used as the block's residual input; its gradient then arrives HERE instead of being summed with the
+    LayerNorm's input gradient by a separate autograd accumulation pass, and the backward kernel adds it in place
+    (cidnet_ln_cf_bwd_res)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _check(x, weight, bias)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib().call("cidnet_ln_cf_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gres):
+        x, weight, mean, rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gw = grad_like(weight)
+        gb = torch.empty_like(weight)
+        if gy is None:                      # only the residual path was used
+            gw.zero_(); gb.zero_()
+            return gres, gw, gb, None
+        gy = _c(gy)
+        gres = _c(gres) if gres is not None else None
+        gx = torch.empty_like(x)
+        n = _raw("cidnet_ln_cf_bwd_ws_floats", C)
+        ws = _ws(n, x.device)
+        lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw), _p(gb), _p(ws),
+                   ws.numel(), B, C, H * W, _stream())
+        return gx, gw, gb, None
+
+
 # --------------------------------------------------------------------------------------------
 # K6/K7: cross-attention block with the residual:  out = x_res + CAB(xn, yn)
 # --------------------------------------------------------------------------------------------

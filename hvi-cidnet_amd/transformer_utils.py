@@ -25,6 +25,13 @@ class LayerNorm(nn.Module):
             raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
         return ops.LayerNormCFFn.apply(x, self.weight, self.bias, self.eps)
 
+    def forward_res(self, x):
+        """(norm(x), x) for a pre-norm residual block: use the second value as the residual input (see
+        ops.LayerNormResFn: the residual's gradient is then added inside the LayerNorm backward kernel)."""
+        if self.data_format != "channels_first":
+            raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
+        return ops.LayerNormResFn.apply(x, self.weight, self.bias, self.eps)
+
 
 class NormDownsample(nn.Module):
     """Reference: net/transformer_utils.py:31-48.  `down` keeps the reference's Sequential(Conv2d,

@@ -70,6 +70,11 @@ long cidnet_ln_cf_bwd_ws_floats(int C);
 int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean,
                      const float* rstd, float* gx, float* gw, float* gb, float* ws, long ws_floats,
                      int B, int C, long HW, void* stream);
+/* same, with gx += addend (the gradient that reaches x through the residual branch of the pre-norm block,
+ * net/LCA.py:79,80,91,92): saves the separate accumulation pass.  addend may be NULL. */
+int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd,
+                         const float* addend, float* gx, float* gw, float* gb, float* ws, long ws_floats, int B, int C,
+                         long HW, void* stream);
 
 /* ---- K4: pointwise (1x1) convolution on the fp32 MFMA -----------------------------------------
  * (nn.Conv2d(k=1): net/LCA.py:13,15,17,51,57; net/transformer_utils.py:60)
