@@ -598,17 +598,28 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
   }
 }
 
+// out[i] = sum_k slabs[k][i]: 8 elements per block, 32 lanes per element striding over the slabs with two
+// independent partial sums (short latency-bound launch), fixed-order fold through LDS
+constexpr int kC3RedElems = 8;
+
 __global__ __launch_bounds__(256) void c3_reduce_kernel(const float* __restrict__ slabs, int n_red, long ne, float* __restrict__ out) {
-  __shared__ float part[8][33];
-  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long i = (long)blockIdx.x * 32 + ex;
-  float t = 0.f;
-  if (i < ne)
-    for (int k = sl; k < n_red; k += 8) t += slabs[(long)k * ne + i];
-  part[sl][ex] = t;
+  __shared__ float part[32][kC3RedElems + 1];
+  const int ex = threadIdx.x & (kC3RedElems - 1), sl = threadIdx.x / kC3RedElems;
+  const long i = (long)blockIdx.x * kC3RedElems + ex;
+  float t0 = 0.f, t1 = 0.f;
+  if (i < ne) {
+    int k = sl;
+    for (; k + 32 < n_red; k += 64) { t0 += slabs[(long)k * ne + i]; t1 += slabs[(long)(k + 32) * ne + i]; }
+    if (k < n_red) t0 += slabs[(long)k * ne + i];
+  }
+  part[sl][ex] = t0 + t1;
   __syncthreads();
-  if (sl == 0 && i < ne)
-    out[i] = ((part[0][ex] + part[1][ex]) + (part[2][ex] + part[3][ex])) + ((part[4][ex] + part[5][ex]) + (part[6][ex] + part[7][ex]));
+  if (sl == 0 && i < ne) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (part[4 * q][ex] + part[4 * q + 1][ex]) + (part[4 * q + 2][ex] + part[4 * q + 3][ex]);
+    out[i] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
 }
 
 // Decomposition of the (M x N) weight-gradient into blocks.  Output channels: equal blocks of <= 48 rows = MT 16-row
@@ -737,7 +748,7 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
     const int rc = c3_thin_wgrad(dY, dy_bs, X, x_bs, replicate, ws, B, M, N, H, W, (hipStream_t)stream);
     if (rc != CIDNET_OK) return rc;
     const long ne = (long)M * N * 9;
-    hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, (hipStream_t)stream, ws,
+    hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + kC3RedElems - 1) / kC3RedElems)), dim3(256), 0, (hipStream_t)stream, ws,
                        B * c3_thin_wgrad_chunks(H, W), ne, dW);
     CIDNET_LAUNCH_STATUS();
     return CIDNET_OK;
@@ -784,7 +795,7 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
 #undef CIDNET_WG_DISPATCH
 #undef CIDNET_WG_LAUNCH
   const long ne = (long)M * N * 9;
-  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + 31) / 32)), dim3(256), 0, s, ws, B * chunks, ne, dW);
+  hipLaunchKernelGGL(c3_reduce_kernel, dim3((unsigned)((ne + kC3RedElems - 1) / kC3RedElems)), dim3(256), 0, s, ws, B * chunks, ne, dW);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -166,6 +166,70 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
   }
 }
 
+// Forward of the IEL middle in one pass (net/LCA.py:61-65): u = dwconv(pin) (2h channels), then the gate
+// g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2).  Run separately, u is written by one kernel and read back by the
+// next; here a lane slides a 3-row, 8-wide window of pin down its strip, forms each row of u on a 6-wide window
+// (own 4 pixels + the 1-pixel halo the gate's convolutions need), stores its own 4 pixels of u (the backward needs u)
+// and the gate row.  HBM traffic: read pin (2h), write u (2h) and g (h): 5h instead of 7h planes.
+template <bool NARROW>
+__global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const float* __restrict__ pin, const float* __restrict__ wdw,
+                                                               const float* __restrict__ w1, const float* __restrict__ w2,
+                                                               float* __restrict__ u, float* __restrict__ g, int B, int h, int H,
+                                                               int W, Tiling tl) {
+  const Item it = decode_item<NARROW>((long)B * h, tl, W);
+  if (!it.live) return;
+  const int c = (int)(it.bc % h);
+  const long b = it.bc / h;
+  float wpa[9], wpb[9], wa[9], wb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wpa[t] = wdw[(long)c * 9 + t]; wpb[t] = wdw[(long)(h + c) * 9 + t];
+    wa[t] = w1[(long)c * 9 + t]; wb[t] = w2[(long)c * 9 + t];
+  }
+  const long HW = (long)H * W;
+  const float* p1 = pin + (b * 2 * h + c) * HW;
+  const float* p2 = pin + (b * 2 * h + h + c) * HW;
+  float* u1 = u + (b * 2 * h + c) * HW;
+  float* u2 = u + (b * 2 * h + h + c) * HW;
+  float* gp = g + it.bc * HW;
+  const int x0 = it.x0, y0 = it.y0, yend = min(y0 + tl.rows, H);
+  // u on the columns x0-1 .. x0+4 of row r, from pin rows r-1, r, r+1 (8-wide); zero outside the image
+  auto u_row = [&](const Win8& a, const Win8& m, const Win8& z, const float (&w)[9], int r) {
+    Win6 o;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float v = w[0] * a.v[i] + w[1] * a.v[i + 1] + w[2] * a.v[i + 2] + w[3] * m.v[i] + w[4] * m.v[i + 1] + w[5] * m.v[i + 2] +
+                      w[6] * z.v[i] + w[7] * z.v[i + 1] + w[8] * z.v[i + 2];
+      const int x = x0 - 1 + i;
+      o.v[i] = (r >= 0 && r < H && x >= 0 && x < W) ? v : 0.f;
+    }
+    return o;
+  };
+  Win8 a0, a1 = load_win8<NARROW>(p1, y0 - 2, x0, H, W), a2 = load_win8<NARROW>(p1, y0 - 1, x0, H, W);
+  Win8 b0, b1 = load_win8<NARROW>(p2, y0 - 2, x0, H, W), b2 = load_win8<NARROW>(p2, y0 - 1, x0, H, W);
+  Win6 ua0, ua1, ub0, ub1;                       // u rows r-2, r-1 of the two channels
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { ua0.v[i] = ua1.v[i] = ub0.v[i] = ub1.v[i] = 0.f; }
+  for (int r = y0 - 1; r <= yend; ++r) {
+    a0 = a1; a1 = a2; a2 = load_win8<NARROW>(p1, r + 1, x0, H, W);
+    b0 = b1; b1 = b2; b2 = load_win8<NARROW>(p2, r + 1, x0, H, W);
+    const Win6 ua2 = u_row(a0, a1, a2, wpa, r), ub2 = u_row(b0, b1, b2, wpb, r);
+    if (r >= y0 && r < yend) {
+      store_px4<NARROW>(u1, r, x0, W, f32x4{ua2.v[1], ua2.v[2], ua2.v[3], ua2.v[4]});
+      store_px4<NARROW>(u2, r, x0, W, f32x4{ub2.v[1], ub2.v[2], ub2.v[3], ub2.v[4]});
+    }
+    const int q = r - 1;                         // gate row q needs u rows q-1, q, q+1
+    if (q >= y0 && q < yend) {
+      const f32x4 c1 = stencil(ua0, ua1, ua2, wa), c2 = stencil(ub0, ub1, ub2, wb);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (tanh_fast(c1[e]) + ua1.v[1 + e]) * (tanh_fast(c2[e]) + ub1.v[1 + e]);
+      store_px4<NARROW>(gp, q, x0, W, o);
+    }
+    ua0 = ua1; ua1 = ua2; ub0 = ub1; ub1 = ub2;
+  }
+}
+
 // gw[c][t] partial over one block of strips of plane (b,c):  sum gout[y][x] * in[y+dy-1][x+dx-1]
 template <bool NARROW>
 __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
@@ -410,6 +474,7 @@ __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int B, in
 // tilings of the kernel families (halo rows re-read per strip: 2 for a stencil, 3 for the fused gate pass;
 // min_lanes = two rounds of the lanes 256 CUs keep resident at each kernel's register footprint)
 inline Tiling fwd_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 2, 256L * 1792 * 2, false); }
+inline Tiling dw_gate_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 4, 256L * 1024 * 2, false); }
 inline Tiling wgrad_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 2, 256L * 1280 * 2, true); }
 inline Tiling gate_bwd_tiling(long planes, int H, int W) { return pick_tiling(planes, H, W, 3, 256L * 512 * 2, true); }
 
@@ -459,6 +524,17 @@ int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float*
   const long items = n_items((long)B * h, tl);
   CIDNET_LAUNCH_NW(W, (iel_gate_kernel<0, true>), (iel_gate_kernel<0, false>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      (hipStream_t)stream, u, w1, w2, (const float*)nullptr, g, (float*)nullptr, (float*)nullptr, B, h, H, W, tl);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g, int B, int h,
+                           int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(pin && wdw && w1 && w2 && u && g && B > 0 && h > 0 && H > 0 && W > 0);
+  const Tiling tl = dw_gate_tiling((long)B * h, H, W);
+  const long items = n_items((long)B * h, tl);
+  CIDNET_LAUNCH_NW(W, (iel_dw_gate_kernel<true>), (iel_dw_gate_kernel<false>), dim3((unsigned)((items + kThreads - 1) / kThreads)),
+                   dim3(kThreads), 0, (hipStream_t)stream, pin, wdw, w1, w2, u, g, B, h, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

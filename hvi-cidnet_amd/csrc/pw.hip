@@ -689,27 +689,35 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   }
 }
 
-// out[o][m*ld + n] (+)= sum_r slabs[(o*n_red + r)][m*N + n].  A block reduces 32 elements with 8 lanes
-// each striding over the slabs, then folds the 8 partials through LDS in a fixed order (reproducible).
+// out[o][m*ld + n] (+)= sum_r slabs[(o*n_red + r)][m*N + n].  A block reduces 8 elements with 32 lanes each striding
+// over the slabs (two independent partial sums per lane keep its loads in flight together: these are short,
+// latency-bound launches), then folds the 32 partials through LDS in a fixed order (reproducible).
+constexpr int kRedElems = 8;
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_red, int M, int N,
                                                            float* __restrict__ out, long out_os, long out_ld, int accumulate) {
-  __shared__ float part[8][33];
+  __shared__ float part[32][kRedElems + 1];
   const long ne = (long)M * N;
-  const int ex = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long i = (long)blockIdx.x * 32 + ex;
+  const int ex = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
+  const long i = (long)blockIdx.x * kRedElems + ex;
   const int o = blockIdx.y;
-  float t = 0.f;
+  float t0 = 0.f, t1 = 0.f;
   if (i < ne) {
     const float* s = slabs + (long)o * n_red * ne + i;
-    for (int rr = sl; rr < n_red; rr += 8) t += s[(long)rr * ne];
+    int rr = sl;
+    for (; rr + 32 < n_red; rr += 64) { t0 += s[(long)rr * ne]; t1 += s[(long)(rr + 32) * ne]; }
+    if (rr < n_red) t0 += s[(long)rr * ne];
   }
-  part[sl][ex] = t;
+  part[sl][ex] = t0 + t1;
   __syncthreads();
   if (sl == 0 && i < ne) {
-    const float v = ((part[0][ex] + part[1][ex]) + (part[2][ex] + part[3][ex])) + ((part[4][ex] + part[5][ex]) + (part[6][ex] + part[7][ex]));
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (part[4 * q][ex] + part[4 * q + 1][ex]) + (part[4 * q + 2][ex] + part[4 * q + 3][ex]);
+    const float tot = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     const int m = (int)(i / N), n = (int)(i - (long)m * N);
     float* dst = out + (long)o * out_os + (long)m * out_ld + n;
-    *dst = accumulate ? *dst + v : v;
+    *dst = accumulate ? *dst + tot : tot;
   }
 }
 
@@ -788,7 +796,7 @@ int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, floa
 #undef WG_CASE
   if (rc != CIDNET_OK) return rc;
   const long ne = (long)M * N;
-  dim3 grid((unsigned)((ne + 31) / 32), per_sample ? (unsigned)B : 1u);
+  dim3 grid((unsigned)((ne + kRedElems - 1) / kRedElems), per_sample ? (unsigned)B : 1u);
   const int n_red = per_sample ? chunks : B * chunks;
   hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, s, ws, n_red, M, N, dW, (long)M * dw_ld, dw_ld, accumulate);
   CIDNET_LAUNCH_STATUS();

@@ -430,9 +430,8 @@ class IELFn(torch.autograd.Function):
         pin = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32)
         pw_conv(xn, 0, C * HW, w_in, 0, 0, C, 1, pin, 0, 2 * h * HW, B, 2 * h, C, HW)
         u = torch.empty_like(pin)
-        dw3x3(pin, w_dw, None, 2 * h, u, B, 2 * h, H, W)
         gate = torch.empty((B, h, H, W), device=dev, dtype=torch.float32)
-        lib().call("cidnet_iel_gate_fwd", _p(u), _p(w_dw1), _p(w_dw2), _p(gate), B, h, H, W, _stream())
+        lib().call("cidnet_iel_dw_gate_fwd", _p(pin), _p(w_dw), _p(w_dw1), _p(w_dw2), _p(u), _p(gate), B, h, H, W, _stream())
         out = torch.empty_like(xn)
         pw_conv(gate, 0, h * HW, w_out, 0, 0, h, 1, out, 0, C * HW, B, C, h, HW, res=res, r_bs=C * HW)
         ctx.save_for_backward(xn, pin, u, gate, w_in, w_dw, w_dw1, w_dw2, w_out)

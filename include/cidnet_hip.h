@@ -114,6 +114,9 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
                      const float* addend, float* gin, float* gw1, float* gw2, float* ws,
                      long ws_floats, int B, int C, int H, int W, void* stream);
 /* g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2);  u: (B,2h,H,W) = [u1;u2], g: (B,h,H,W). */
+/* u = dw3x3(pin, wdw) (2h channels) and g = gate(u) in one pass (net/LCA.py:61-65): u is written once and never re-read */
+int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g,
+                           int B, int h, int H, int W, void* stream);
 int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h,
                         int H, int W, void* stream);
 /* da = d(dw1/2 output), ds = d(s1/s2) both (B,2h,H,W); du = ds + dw3x3(da, flipped) by the caller. */

@@ -173,3 +173,20 @@ def test_iel_gate_dw_bwd_fused_equals_unfused(dev, B, h, H, W):
     close(du, du_ref, what="du")
     close(g1, g1_ref, what="gw1")
     close(g2, g2_ref, what="gw2")
+
+
+@pytest.mark.parametrize("B,h,H,W", [(2, 5, 9, 13), (1, 31, 16, 24), (2, 127, 4, 6), (1, 7, 3, 3), (1, 63, 8, 12), (1, 95, 40, 300), (1, 3, 50, 75)])
+def test_iel_dw_gate_fwd_fused_equals_unfused(dev, B, h, H, W):
+    """fused dwconv + gate forward == depthwise conv followed by the gate kernel (both outputs)"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    pin = rnd(61, (B, 2 * h, H, W), 1.5).to(dev)
+    w, w1, w2 = rnd(62, (2 * h, 1, 3, 3), 0.4).to(dev), rnd(63, (h, 1, 3, 3), 0.5).to(dev), rnd(64, (h, 1, 3, 3), 0.5).to(dev)
+    u_ref = torch.empty_like(pin)
+    ops.dw3x3(pin, w, None, 2 * h, u_ref, B, 2 * h, H, W)
+    g_ref = torch.empty((B, h, H, W), device=dev)
+    lib().call("cidnet_iel_gate_fwd", ops._p(u_ref), ops._p(w1), ops._p(w2), ops._p(g_ref), B, h, H, W, ops._stream())
+    u, g = torch.empty_like(pin), torch.empty_like(g_ref)
+    lib().call("cidnet_iel_dw_gate_fwd", ops._p(pin), ops._p(w), ops._p(w1), ops._p(w2), ops._p(u), ops._p(g), B, h, H, W, ops._stream())
+    close(u, u_ref, what="u")
+    close(g, g_ref, what="gate")
