@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
     ap.add_argument("--op-rows", type=int, default=70, help="rows of the per-shape part of --op-table")
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient GEMMs on the branch streams")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the I and HV branches on one stream (default: two streams, kernels of the two branches overlap)")
     return ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream
-    trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4)
+    trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream))
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     shape = (a.batch, 3, a.height, a.width)
@@ -142,12 +143,15 @@ def main():
     # They run single-stream so that an event pair brackets ONE kernel family at a time: with the two branch
     # streams of the timed region, launches of different families overlap and an event pair would charge a
     # kernel for the time it shares the GPU with the other branch.
+    from hvi_cidnet_amd import ops as _ops
     model.two_streams = False
+    _ops.enable_wgrad_stream(False)
     timer = OpTimer().install() if rank == 0 else None
     for _ in range(2):
         trainer.step(x, gt)
     sync()
     model.two_streams = not a.single_stream
+    _ops.enable_wgrad_stream(trainer.wgrad_stream)
     if rank == 0:
         agg = timer.table()
         timer.remove()
@@ -179,7 +183,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CIDNet fwd+bwd bs={a.batch}/GPU 3x{a.height}x{a.width} fp32 (BASELINE.json configs[1])",
-                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "streams": 1 if a.single_stream else 2, "loss": round(lossv, 6)},
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
