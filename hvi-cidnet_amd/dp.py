@@ -86,6 +86,8 @@ class DataParallelTrainer:
         self._opt_args = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._ready = False
         self._handles: List = []
+        self._launch_stream = None
+        self._main_stream = None
         self.params = [p for p in model.parameters() if p.requires_grad]
 
     # ---- one-time setup: probe gradient order, flatten, hook -----------------------------------
@@ -178,8 +180,30 @@ class DataParallelTrainer:
         bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and (self.world > 1 or self._force_comm):
-            start, cnt, _ = self.buckets[bi]
-            self._join_wgrad_stream()               # the bucket's last weight gradients may still be in flight
+            self._launch_bucket(bi)
+
+    def _launch_bucket(self, bi):
+        """All-reduce one finished bucket without stalling the compute streams.  The bucket's gradients were written
+        by kernels on up to three streams (the two branch streams and the weight-gradient stream) and this hook only
+        runs in CPU order, so the collective is issued from a dedicated launch stream that first waits for the
+        current tail of every producer stream; RCCL orders its own stream after the launch stream."""
+        start, cnt, _ = self.buckets[bi]
+        dev = self.flat_g.device
+        if dev.type != "cuda":                    # gloo / CPU rehearsal: no streams
+            self._handles.append(dist.all_reduce(self.flat_g[start:start + cnt], op=dist.ReduceOp.SUM, group=self.pg,
+                                                 async_op=True))
+            return
+        if self._launch_stream is None:
+            self._launch_stream = torch.cuda.Stream(device=dev)
+        st = self._launch_stream
+        producers = [torch.cuda.current_stream(), self._main_stream, getattr(self.model, "_side_stream", None)]
+        if self.use_hip and self.wgrad_stream:
+            from . import ops
+            producers.append(ops.wgrad_stream(dev))
+        for ps in producers:
+            if ps is not None:
+                st.wait_stream(ps)
+        with torch.cuda.stream(st):
             self._handles.append(dist.all_reduce(self.flat_g[start:start + cnt], op=dist.ReduceOp.SUM, group=self.pg,
                                                  async_op=True))
 
@@ -191,6 +215,7 @@ class DataParallelTrainer:
         for bi, (_, _, mem) in enumerate(self.buckets):
             self._pending[bi] = len(mem)
         self._handles = []
+        self._main_stream = torch.cuda.current_stream() if x.is_cuda else None
         loss = self.loss_fn(self.model(x), gt)
         loss.backward()
         for h in self._handles:
@@ -206,6 +231,7 @@ class DataParallelTrainer:
         for bi, (_, _, mem) in enumerate(self.buckets):
             self._pending[bi] = len(mem)
         self._handles = []
+        self._main_stream = torch.cuda.current_stream() if x.is_cuda else None
         loss = self.loss_fn(self.model(x), gt)
         loss.backward()
         for h in self._handles:

@@ -79,3 +79,39 @@ def test_trainer_gradients_and_update_match_plain_autograd(dev, chans, shape):
         assert torch.allclose(p, t, atol=1e-7, rtol=1e-6), n
     ops.set_grad_arena(None, None)
     ops.enable_wgrad_stream(False)
+
+
+def test_trainer_rccl_path_on_one_rank(dev, monkeypatch):
+    """The multi-GPU code path (bucket all-reduces launched from gradient hooks, joined with the weight-gradient
+    stream, 1/world folded into Adam) exercised on ONE rank over RCCL: a 1-rank all-reduce is the identity, so
+    gradients and the update must equal the no-communication run bit for bit."""
+    import torch.distributed as dist
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    chans, shape = (12, 12, 24, 48), (2, 3, 32, 48)
+    x = O.synthetic_batch(41, shape).to(dev)
+    gt = O.synthetic_batch(42, shape).to(dev)
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
+    m0 = _model(dev, chans)
+    t0 = DataParallelTrainer(m0, lr=1e-3, n_buckets=3)
+    t0.step(x, gt)
+    torch.cuda.synchronize()
+    ref_g = t0.flat_g.clone()
+    ref_p = t0.flat_p.clone()
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
+    monkeypatch.setenv("CIDNET_DP_FORCE_ALLREDUCE", "1")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29571", world_size=1, rank=0)
+    try:
+        m1 = _model(dev, chans)
+        t1 = DataParallelTrainer(m1, lr=1e-3, n_buckets=3)
+        t1.step(x, gt)
+        torch.cuda.synchronize()
+        assert t1._handles == [] or all(h.is_completed() for h in t1._handles)
+        assert torch.equal(t1.flat_g, ref_g)
+        assert torch.equal(t1.flat_p, ref_p)
+    finally:
+        dist.destroy_process_group()
+        ops.set_grad_arena(None, None)
+        ops.enable_wgrad_stream(False)
