@@ -158,7 +158,9 @@ def main():
         agg = timer.table()
         timer.remove()
         tot = sum(v[1] for v in agg.values())
-        c3 = [(args, e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if name == "cidnet_conv3x3"]
+        # the MFMA kernel only: the <= 4-channel stem / head launches of cidnet_conv3x3 run on streaming VALU kernels
+        c3 = [(args, e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
+              if name == "cidnet_conv3x3" and min(args[10], args[11]) > 4]
         c3_flops = sum(conv3x3_flops(ar) for ar, _ in c3)
         c3_ms = sum(ms for _, ms in c3)
         achieved = c3_flops / (c3_ms * 1e-3) / 1e12 if c3_ms > 0 else 0.0
@@ -168,7 +170,7 @@ def main():
             print(f"  sum of kernel families: {tot / 2:.3f} ms/step; wall {1e3 * dt / a.steps:.3f} ms/step", file=sys.stderr)
             for k, v in sorted(timer.table(by_shape=True).items(), key=lambda kv: -kv[1][1])[:a.op_rows]:
                 print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
-        roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad)",
+        roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad, MFMA launches)",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                 "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
@@ -196,7 +198,7 @@ def main():
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_conv3_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction);
+    (profiles/r01_pmc_conv3_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction);
     counters cannot be read from inside this process, so this is null if the summary is absent."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv3_traffic.json")))
