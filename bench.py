@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
     ap.add_argument("--op-rows", type=int, default=70, help="rows of the per-shape part of --op-table")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient GEMMs on the branch streams")
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (experiment)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the I and HV branches on one stream (default: two streams, kernels of the two branches overlap)")
     return ap.parse_args()
@@ -112,7 +113,8 @@ def main():
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream
-    trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream))
+    trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream),
+                                  use_graph=a.graph)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     shape = (a.batch, 3, a.height, a.width)
@@ -148,11 +150,13 @@ def main():
     from hvi_cidnet_amd import ops as _ops
     model.two_streams = False
     _ops.enable_wgrad_stream(False)
+    graph_mode, trainer.use_graph = trainer.use_graph, False      # the instrumented steps launch eagerly
     timer = OpTimer().install() if rank == 0 else None
     for _ in range(2):
         trainer.step(x, gt)
     sync()
     model.two_streams = not a.single_stream
+    trainer.use_graph = graph_mode
     _ops.enable_wgrad_stream(trainer.wgrad_stream)
     if rank == 0:
         agg = timer.table()

@@ -119,6 +119,51 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_reg_kernel(const float* __res
   }
 }
 
+// Wide C on small planes (C = 144 on 50x75): one lane per pixel would hold 144 channels (437 VGPRs, one wave per
+// SIMD) and the whole level is only 30 000 pixels = 0.46 waves per SIMD.  Here FOUR adjacent lanes share a pixel,
+// each keeps C/4 channels in registers, and the two channel sums are combined across the quad (xor 1, xor 2):
+// four times the lanes at a quarter of the registers.
+template <int CQ, bool CACHE_G>
+__global__ __launch_bounds__(kThreads) void ln_bwd_quad_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ gy, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ addend,
+                                                               float* __restrict__ gx, int B, long HW) {
+  constexpr int C = 4 * CQ;
+  const long total = (long)B * HW;
+  const float invC = 1.0f / (float)C;
+  const int q = threadIdx.x & 3;
+  for (long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 2; it < total; it += ((long)gridDim.x * blockDim.x) >> 2) {
+    const long b = it / HW, p = it - b * HW;
+    // uniform channel pointer + one 32-bit per-lane offset (the launcher checks B*C*HW < 2^31): a single offset
+    // register serves all 2*CQ loads instead of a 64-bit address pair each
+    const unsigned off = (unsigned)((b * C + (long)q * CQ) * HW + p);
+    const float* wq = w + q * CQ;
+    const float u = mean[b * HW + p], rs = rstd[b * HW + p];
+    float xh[CQ], gw[CACHE_G ? CQ : 1];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) xh[c] = (x + (long)c * HW)[off];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      const float g = (gy + (long)c * HW)[off] * wq[c];
+      if (CACHE_G) gw[c] = g;
+      xh[c] = (xh[c] - u) * rs;
+      s1 += g;
+      s2 += g * xh[c];
+    }
+    s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+    s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+    s1 *= invC; s2 *= invC;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      const float g = CACHE_G ? gw[c] : (gy + (long)c * HW)[off] * wq[c];
+      float o = rs * (g - s1 - xh[c] * s2);
+      if (addend) o += (addend + (long)c * HW)[off];
+      (gx + (long)c * HW)[off] = o;
+    }
+  }
+}
+
 // ---- generic multi-pass kernels (any C, any HW) ---------------------------------------------------
 __device__ __forceinline__ f32x4 ld4(const float* row, long p, int n) {
   if (n == 4) return load4u(row + p);
@@ -281,6 +326,9 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
     else if (C == 72)
       hipLaunchKernelGGL((ln_bwd_reg_kernel<72, 1, true>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, gy, mean,
                          rstd, addend, gx, B, HW);
+    else if (C == 144 && (long)B * C * HW < (1L << 31) && (long)B * HW <= (1L << 18))      // small planes: four lanes per pixel
+      hipLaunchKernelGGL((ln_bwd_quad_kernel<36, true>), dim3(grid_for((long)B * HW * 4)), dim3(kThreads), 0, s, x, weight, gy,
+                         mean, rstd, addend, gx, B, HW);
     else if (C == 144)
       hipLaunchKernelGGL((ln_bwd_reg_kernel<144, 1, false>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, gy,
                          mean, rstd, addend, gx, B, HW);

@@ -115,3 +115,26 @@ def test_trainer_rccl_path_on_one_rank(dev, monkeypatch):
         dist.destroy_process_group()
         ops.set_grad_arena(None, None)
         ops.enable_wgrad_stream(False)
+
+
+def test_trainer_graph_replay_equals_eager(dev):
+    """forward + loss + backward replayed as one hipGraph (three streams captured) must give the eager step's
+    gradients and parameter updates bit for bit, step after step (new inputs are copied into the static buffers)."""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    chans, shape = (12, 12, 24, 48), (2, 3, 32, 48)
+    batches = [(O.synthetic_batch(51 + i, shape).to(dev), O.synthetic_batch(61 + i, shape).to(dev)) for i in range(3)]
+    res = []
+    for use_graph in (False, True):
+        ops.set_grad_arena(None, None)
+        ops.enable_wgrad_stream(False)
+        m = _model(dev, chans)
+        tr = DataParallelTrainer(m, lr=1e-3, n_buckets=3, use_graph=use_graph)
+        losses = [float(tr.step(x, gt).item()) for x, gt in batches]
+        torch.cuda.synchronize()
+        res.append((losses, tr.flat_g.clone(), tr.flat_p.clone()))
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
