@@ -249,6 +249,9 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
               }
             }
           }
+        // ... and keep the NEXT group's window finishing (which waits for those loads) behind the burst: without this
+        // fence the scheduler pulls the selects, and with them the s_waitcnt, up between the first MFMAs
+        if (!NARROW) __builtin_amdgcn_sched_barrier(0);
       }
     }
 
