@@ -131,27 +131,76 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   const bool rep = a.replicate != 0;
   const bool single = a.K <= kKC;               // whole weight panel resident: walk `tpb` row tiles
 
-  // consecutive threads walk the contiguous axis of the weight tensor ((k,tap) for the forward
-  // layout, (m,tap) for the data-gradient layout): full-line fetches instead of 4-byte gathers
+  // Weight panel -> LDS.  Consecutive threads walk the contiguous axis of the weight tensor ((k,tap) for the forward
+  // layout, (m,tap) for the data-gradient layout) with 16 B loads: a thread takes 4 consecutive elements of a row,
+  // decodes them with constant divisors and scatters them to [k][tap][m].  (One 4 B load + two run-time integer
+  // divisions per element made this staging cost half a tile's MFMA time.)
   auto stage = [&](int kc0, int kcn, int ng) {
     const int kq = ng * 4;
     if (a.w_ks == 9) {
-      for (int i = tid; i < MB * kq * 9; i += kThreads) {
-        const int mm = i / (kq * 9), rem = i - mm * (kq * 9);
-        const int kk = rem / 9, t = rem - kk * 9;
-        float v = 0.f;
-        if (kk < kcn && m0 + mm < a.M)
-          v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * 9 + (a.flip ? 8 - t : t)];
-        As[(kk * 9 + t) * ldA + mm] = v;
+      const int rowlen = kq * 9, nv = (rowlen + 3) >> 2, valid = kcn * 9;      // per output channel: (k,tap) run
+      for (int i = tid; i < MB * nv; i += kThreads) {
+        const int mm = i / nv, v = i - mm * nv;
+        const int e0 = 4 * v;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + mm < a.M) {
+          const float* src = a.Wt + (long)(m0 + mm) * a.w_ms + (long)kc0 * 9 + e0;
+          if (e0 + 3 < valid) {
+            const f32x4 q = load4u(src);
+            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (e0 + q < valid) x[q] = src[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = e0 + q;
+          if (e < rowlen) {
+            const int kk = e / 9, t = e - kk * 9;
+            As[(kk * 9 + (a.flip ? 8 - t : t)) * ldA + mm] = x[q];
+          }
+        }
       }
     } else {
-      for (int i = tid; i < kq * MB * 9; i += kThreads) {
-        const int kk = i / (MB * 9), rem = i - kk * (MB * 9);
-        const int mm = rem / 9, t = rem - mm * 9;
-        float v = 0.f;
-        if (kk < kcn && m0 + mm < a.M)
-          v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
-        As[(kk * 9 + t) * ldA + mm] = v;
+      // data-gradient layout: Wt[(m0+mm)*9 + (kc0+kk)*w_ks + tap] (w_ms == 9): for one kk the run over (mm,tap) is contiguous
+      const int rowlen = MB * 9, nv = (rowlen + 3) >> 2;
+      const int valid = (a.M - m0 < MB ? a.M - m0 : MB) * 9;
+      if (a.w_ms != 9) {                          // generic strides: element-wise
+        for (int i = tid; i < kq * MB * 9; i += kThreads) {
+          const int kk = i / (MB * 9), rem = i - kk * (MB * 9);
+          const int mm = rem / 9, t = rem - mm * 9;
+          float v = 0.f;
+          if (kk < kcn && m0 + mm < a.M)
+            v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
+          As[(kk * 9 + t) * ldA + mm] = v;
+        }
+        return;
+      }
+      for (int i = tid; i < kq * nv; i += kThreads) {
+        const int kk = i / nv, v = i - kk * nv;
+        const int e0 = 4 * v;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kk < kcn) {
+          const float* src = a.Wt + (long)m0 * 9 + (long)(kc0 + kk) * a.w_ks + e0;
+          if (e0 + 3 < valid) {
+            const f32x4 q = load4u(src);
+            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (e0 + q < valid) x[q] = src[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = e0 + q;
+          if (e < rowlen) {
+            const int mm = e / 9, t = e - mm * 9;
+            As[(kk * 9 + (a.flip ? 8 - t : t)) * ldA + mm] = x[q];
+          }
+        }
       }
     }
   };
@@ -335,8 +384,13 @@ int launch_c3x(C3Args a, int B, hipStream_t s) {
   const int ntiles = (a.H + 4 * NY * kR - 1) / (4 * NY * kR);
   long tpb = 1;
   if (a.K <= kKC) {                              // weights stay resident: walk several row tiles per block
-    tpb = (long)xt * ntiles * B * a.nmb / 2048;
+    // staging the (<= 46 KB) weight panel costs a good part of a tile's MFMA time: amortise it over several tiles, but
+    // only while >= two rounds of resident blocks remain (tools/micro_c3.py, 36->36: 4000 tiles 494/457/456 us at
+    // 1/2/4 tiles per block; 1000 tiles 166/169/238 us); timing study: bits 8..15 of the debug flags force tpb
+    const long tiles = (long)xt * ntiles * B * a.nmb;
+    tpb = tiles / 1024;
     tpb = tpb < 1 ? 1 : (tpb > 4 ? 4 : tpb);
+    if ((g_c3_dbg >> 8) & 0xFF) tpb = (g_c3_dbg >> 8) & 0xFF;
   }
   a.tpb = (int)tpb;
   dim3 grid((unsigned)xt, (unsigned)((ntiles + tpb - 1) / tpb), (unsigned)(B * a.nmb));

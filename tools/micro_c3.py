@@ -21,6 +21,8 @@ def run(B, M, K, H, W, flags, iters=10):
 
 for sh in [(8, 36, 36, 400, 600), (8, 36, 36, 200, 300), (8, 72, 36, 200, 300), (8, 36, 72, 200, 300), (8, 144, 72, 100, 150), (8, 72, 144, 100, 150), (8, 72, 144, 50, 75)]:
     r = {f: run(*sh, flags=f) for f in (0, 1, 2, 3, 4, 7, 16)}
+    tp = {t: run(*sh, flags=t << 8)[0] for t in (1, 2, 4, 8)}
+    print(f"   tiles/block sweep {sh}: " + " ".join(f"{k}:{v:.0f}" for k, v in tp.items()))
     print(f"{sh}: full {r[0][0]:7.1f} us {r[0][1]:5.1f} TF | no-store {r[1][0]:7.1f} | no-load {r[2][0]:7.1f} | neither {r[3][0]:7.1f} | const-w {r[4][0]:7.1f} | mfma-only {r[7][0]:7.1f} ({r[7][1]:.1f} TF) | padded-tiles {r[16][0]:7.1f}")
 
 def run_wg(B, M, N, H, W, flags, iters=10):
