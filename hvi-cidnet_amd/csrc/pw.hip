@@ -105,15 +105,47 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   const long tile_beg = a.tile0 + (long)blockIdx.x * a.tpb;
   const long tile_end = min(tile_beg + a.tpb, (long)a.ntile_lim);
 
-  // consecutive threads follow the unit-stride axis of the weight tensor (k for the forward layout,
-  // m for the transposed / data-gradient layout), so the panel is fetched in full cache lines
+  // Weight panel -> LDS as [k][m].  Consecutive threads follow the unit-stride axis of the weight tensor (k for the
+  // forward layout, m for the transposed / data-gradient layout) with 16 B loads where the strides allow it: a thread
+  // takes 4 consecutive elements of a run.  (One 4 B load and a run-time division per element cost ~10 % of a block.)
   auto stage = [&](int kc0, int kcn, int kcn4) {
     if (a.w_ks == 1) {
-      for (int i = tid; i < kcn4 * MB; i += kThreads) {
-        const int mm = i / kcn4, kk = i - mm * kcn4;
-        float v = 0.f;
-        if (kk < kcn && m0 + mm < a.M) v = Wb[(long)(m0 + mm) * a.w_ms + (kc0 + kk)];
-        As[kk * ldA + mm] = v;
+      const int nv = kcn4 >> 2;                                   // float4 groups along k per output channel
+      for (int i = tid; i < nv * MB; i += kThreads) {
+        const int mm = i / nv, k0 = (i - mm * nv) << 2;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + mm < a.M) {
+          const float* src = Wb + (long)(m0 + mm) * a.w_ms + (kc0 + k0);
+          if (k0 + 3 < kcn) {
+            const f32x4 q = load4u(src);
+            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (k0 + q < kcn) x[q] = src[q];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) As[(k0 + q) * ldA + mm] = x[q];
+      }
+    } else if (a.w_ms == 1) {
+      const int nv = MB >> 2;                                     // float4 groups along m per k (MB is a multiple of 16)
+      const int mvalid = a.M - m0;
+      for (int i = tid; i < kcn4 * nv; i += kThreads) {
+        const int kk = i / nv, mm0 = (i - kk * nv) << 2;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kk < kcn) {
+          const float* src = Wb + (long)(m0 + mm0) + (long)(kc0 + kk) * a.w_ks;
+          if (mm0 + 3 < mvalid) {
+            const f32x4 q = load4u(src);
+            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (mm0 + q < mvalid) x[q] = src[q];
+          }
+        }
+        *reinterpret_cast<f32x4*>(&As[kk * ldA + mm0]) = f32x4{x[0], x[1], x[2], x[3]};
       }
     } else {
       for (int i = tid; i < kcn4 * MB; i += kThreads) {
