@@ -767,7 +767,26 @@ inline int pick_tiles(int dim, int maxt) {   // tiles per block for a dimension 
   return (T + nblk - 1) / nblk;
 }
 
-inline int wgrad_pch(long HW) { return HW >= 16384 ? 1024 : 512; }
+int g_wg_force_pch = 0;          // timing studies (cidnet_debug_pw_flags bit 7 set: bits 8.. = pixels per block / 128)
+
+// Pixels per block of the weight-gradient kernel (multiple of 128 = one step of the block's four waves).  A block costs
+// its pixel steps plus about 6 steps' worth of prologue / LDS reduction / slab write, and 256 CUs hold 512 blocks at a
+// time, so the launch costs about ceil(blocks / 512) * (steps + 6): take the cheapest of a few sizes.
+inline int wgrad_pch(int B, int M, int N, long HW) {
+  if (g_wg_force_pch > 0) return g_wg_force_pch;
+  if (g_pw_dbg & 64) return HW >= 16384 ? 1024 : 512;            // previous fixed rule (A/B runs)
+  const int MT = pick_tiles(M, 3), NT = pick_tiles(N, 3);
+  const long per_chunk = (long)B * (((M + 15) / 16 + MT - 1) / MT) * (((N + 15) / 16 + NT - 1) / NT);
+  int best = 512;
+  long best_cost = -1;
+  for (int pch : {512, 768, 1024, 1536, 2048, 3072, 4096}) {
+    if (pch > 512 && pch > HW) break;
+    const long blocks = per_chunk * ((HW + pch - 1) / pch);
+    const long cost = ((blocks + 511) / 512) * (pch / 128 + 6);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = pch; }
+  }
+  return best;
+}
 
 }  // namespace
 }  // namespace cidnet
@@ -779,6 +798,8 @@ extern "C" {
 void cidnet_debug_pw_flags(int flags) {
   g_pw_dbg = flags & 0xFF;
   g_pw_force_mt = (flags >> 28) & 7;
+  if (flags & 128) { g_wg_force_pch = 128 * ((flags >> 8) & 0xFFFFF); return; }
+  g_wg_force_pch = 0;
   g_pw_target_set = ((flags >> 8) & 0xFFFFF) != 0;
   g_pw_target_blocks = g_pw_target_set ? (flags >> 8) & 0xFFFFF : 512;
 }
@@ -804,7 +825,7 @@ int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_m
 }
 
 long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW) {
-  const int pch = wgrad_pch(HW);
+  const int pch = wgrad_pch(B, M, N, HW);
   const long chunks = (HW + pch - 1) / pch;
   return (long)B * chunks * M * N;
 }
@@ -815,7 +836,7 @@ int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, floa
   if (ws_floats < cidnet_pw_wgrad_ws_floats(B, M, N, HW)) return CIDNET_ERR_WS;
   WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.HW = HW;
-  a.pch = wgrad_pch(HW);
+  a.pch = wgrad_pch(B, M, N, HW);
   const int chunks = (int)((HW + a.pch - 1) / a.pch);
   const int MT = pick_tiles(M, 3), NT = pick_tiles(N, 3);
   const int nmb = ((M + 15) / 16 + MT - 1) / MT;

@@ -82,7 +82,8 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
  *   A_b[m][k] = Wt[b*w_bs + m*w_ms + k*w_ks]   (w_bs = 0: shared weights; forward: w_ms=K,w_ks=1;
  *   data gradient: w_ms=1, w_ks=<Cin>), X[b] at X + b*x_bs with channel stride HW (same for Y, R),
  *   so channel slices of wider tensors can be read / written in place.  R may alias Y. */
-/* timing-study switches for cidnet_pw_conv (bit0: no stores, bit1: no K loop); 0 = production */
+/* timing-study switches for cidnet_pw_conv (bit0: no stores, bit1: no K loop; bit7: force the weight-gradient
+ * kernel to (flags >> 8) * 128 pixels per block); 0 = production */
 void cidnet_debug_pw_flags(int flags);
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
                    float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
