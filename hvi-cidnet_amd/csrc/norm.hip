@@ -8,6 +8,7 @@
 // covers other widths.  The backward is two kernels: a per-pixel one (gx; reads x, gy once) and a
 // channel-major one (d weight, d bias; block = one channel x one pixel chunk, fixed-order two-level
 // sum => bitwise reproducible, no atomics).
+#include <cstdlib>
 #include "common.h"
 
 namespace cidnet {
@@ -21,6 +22,12 @@ template <> struct Vec<4> {
   typedef f32x4 T;
   static __device__ __forceinline__ T ld(const float* p) { return load4u(p); }
   static __device__ __forceinline__ void st(float* p, T v) { store4u(p, v); }
+  static __device__ __forceinline__ float hsum(T v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+  static __device__ __forceinline__ T quad_sum(T v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += __shfl_xor(v[e], 1); v[e] += __shfl_xor(v[e], 2); }
+    return v;
+  }
 };
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -28,12 +35,20 @@ template <> struct Vec<2> {
   typedef f32x2 T;
   static __device__ __forceinline__ T ld(const float* p) { f2u v = *reinterpret_cast<const f2u*>(p); T r = {v.x, v.y}; return r; }
   static __device__ __forceinline__ void st(float* p, T v) { f2u s; s.x = v[0]; s.y = v[1]; *reinterpret_cast<f2u*>(p) = s; }
+  static __device__ __forceinline__ float hsum(T v) { return v[0] + v[1]; }
+  static __device__ __forceinline__ T quad_sum(T v) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { v[e] += __shfl_xor(v[e], 1); v[e] += __shfl_xor(v[e], 2); }
+    return v;
+  }
 };
 typedef float f32x1 __attribute__((ext_vector_type(1)));
 template <> struct Vec<1> {
   typedef float T;
   static __device__ __forceinline__ T ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ float hsum(T v) { return v; }
+  static __device__ __forceinline__ T quad_sum(T v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
 };
 template <int VEC> __device__ __forceinline__ typename Vec<VEC>::T vrsqrt_eps(typename Vec<VEC>::T v, float invC, float eps);
 template <> __device__ __forceinline__ float vrsqrt_eps<1>(float v, float invC, float eps) { return 1.0f / sqrtf(v * invC + eps); }
@@ -161,6 +176,97 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_kernel(const float* __re
       if (addend) o += (addend + (long)c * HW)[off];
       (gx + (long)c * HW)[off] = o;
     }
+  }
+}
+
+// Whole LayerNorm backward in ONE pass for C = 36 / 72: gx, and the per-block partial sums of d weight[c] = sum gy*xhat
+// and d bias[c] = sum gy (the separate ln_wb_kernel pass re-read x and gy: 5 tensor passes instead of 3).  With one
+// lane per pixel column the extra 2C accumulators do not fit (264 / 360 VGPRs when tried), so FOUR adjacent lanes
+// share a pixel vector and each keeps C/4 channels: x-hat, g*w and the accumulators are CQ*VEC + CQ*VEC + 2*CQ
+// registers, and the two channel sums are combined across the quad.  part: [gridDim.x][2C] = (dw | db) per block.
+template <int CQ, int VEC>
+__global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ gy, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, const float* __restrict__ addend,
+                                                                     float* __restrict__ gx, float* __restrict__ part, int B, long HW) {
+  typedef typename Vec<VEC>::T V;
+  constexpr int C = 4 * CQ;
+  __shared__ float red[(kThreads / 64) * 4 * 2 * CQ];
+  const long nq = HW / VEC;
+  const long total = (long)B * nq;
+  const float invC = 1.0f / (float)C;
+  const int q = threadIdx.x & 3;
+  const float* wq = w + q * CQ;
+  float aw[CQ], ab[CQ];
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) { aw[c] = 0.f; ab[c] = 0.f; }
+  for (long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 2; it < total; it += ((long)gridDim.x * blockDim.x) >> 2) {
+    const long b = it / nq, p = (it - b * nq) * VEC;
+    const long base = (b * C + (long)q * CQ) * HW + p;
+    const float* xb = x + base;
+    const float* gb = gy + base;
+    const V u = Vec<VEC>::ld(mean + b * HW + p), rs = Vec<VEC>::ld(rstd + b * HW + p);
+    V xh[CQ], gw[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) xh[c] = Vec<VEC>::ld(xb + (long)c * HW);
+    V s1 = u * 0.f, s2 = s1;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      const V g = Vec<VEC>::ld(gb + (long)c * HW);
+      xh[c] = (xh[c] - u) * rs;
+      aw[c] += Vec<VEC>::hsum(g * xh[c]);
+      ab[c] += Vec<VEC>::hsum(g);
+      gw[c] = g * wq[c];
+      s1 += gw[c];
+      s2 += gw[c] * xh[c];
+    }
+    s1 = Vec<VEC>::quad_sum(s1) * invC;
+    s2 = Vec<VEC>::quad_sum(s2) * invC;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      V o = rs * (gw[c] - s1 - xh[c] * s2);
+      if (addend) o += Vec<VEC>::ld(addend + base + (long)c * HW);
+      Vec<VEC>::st(gx + base + (long)c * HW, o);
+    }
+  }
+  // lanes with equal q: butterfly over the other lane bits, then the four waves through LDS (fixed order)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) {
+    float a = aw[c], d = ab[c];
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { a += __shfl_xor(a, m); d += __shfl_xor(d, m); }
+    if (lane < 4) { red[(wave * 4 + q) * 2 * CQ + c] = a; red[(wave * 4 + q) * 2 * CQ + CQ + c] = d; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
+    const int which = i / C, ch = i - which * C;           // 0: dw, 1: db
+    const int qq = ch / CQ, k = ch - qq * CQ;
+    const int o = qq * 2 * CQ + which * CQ + k;
+    part[(long)blockIdx.x * 2 * C + i] = (red[o] + red[8 * CQ + o]) + (red[16 * CQ + o] + red[24 * CQ + o]);
+  }
+}
+
+// gw[c], gb[c] = sum over blocks of part[blk][c], part[blk][C + c]: 8 outputs per block, 32 lanes per output
+__global__ __launch_bounds__(256) void ln_wb2_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ gw,
+                                                            float* __restrict__ gb) {
+  __shared__ float fold[32][9];
+  const int ex = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + ex;
+  float t0 = 0.f, t1 = 0.f;
+  if (i < 2 * C) {
+    int k = sl;
+    for (; k + 32 < nblk; k += 64) { t0 += part[(long)k * 2 * C + i]; t1 += part[(long)(k + 32) * 2 * C + i]; }
+    if (k < nblk) t0 += part[(long)k * 2 * C + i];
+  }
+  fold[sl][ex] = t0 + t1;
+  __syncthreads();
+  if (sl == 0 && i < 2 * C) {
+    float v[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v[g] = (fold[4 * g][ex] + fold[4 * g + 1][ex]) + (fold[4 * g + 2][ex] + fold[4 * g + 3][ex]);
+    const float tot = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    if (i < C) gw[i] = tot; else gb[i - C] = tot;
   }
 }
 
@@ -310,7 +416,13 @@ int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, flo
   return CIDNET_OK;
 }
 
-long cidnet_ln_cf_bwd_ws_floats(int C) { return 2L * 2048 + 4L * C * 64; }
+constexpr int kFusedBlocks = 1024;   // blocks of ln_bwd_quad_fused_kernel
+bool g_ln_unfused = false;           // A/B switch (environment CIDNET_LN_UNFUSED=1 at first use)
+
+long cidnet_ln_cf_bwd_ws_floats(int C) {
+  const long a = 2L * 2048 + 4L * C * 64, b = 2L * C * kFusedBlocks;
+  return a > b ? a : b;
+}
 
 int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd,
                          const float* addend, float* gx, float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW,
@@ -318,7 +430,23 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
   CIDNET_CHECK_ARG(x && weight && gy && mean && rstd && gw && gb && ws && B > 0 && C > 0 && HW > 0);
   const int nchunk = wb_chunks(B, C, HW);
   if (ws_floats < 2L * C * nchunk) return CIDNET_ERR_WS;
+  static const bool env_read = (g_ln_unfused = std::getenv("CIDNET_LN_UNFUSED") != nullptr, true);
+  (void)env_read;
   hipStream_t s = (hipStream_t)stream;
+  if (gx && ((C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0)) && ws_floats >= 2L * C * kFusedBlocks && !g_ln_unfused) {
+    const long lanes = (C == 36 ? (long)B * HW / 4 : (long)B * HW / 2) * 4;
+    const int nblk = (int)((lanes + kThreads - 1) / kThreads < kFusedBlocks ? (lanes + kThreads - 1) / kThreads : kFusedBlocks);
+    if (C == 36)
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx, ws,
+                         B, HW);
+    else
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
+                         ws, B, HW);
+    CIDNET_LAUNCH_STATUS();
+    hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb);
+    CIDNET_LAUNCH_STATUS();
+    return CIDNET_OK;
+  }
   if (gx) {
     if (C == 36 && HW % 2 == 0)
       hipLaunchKernelGGL((ln_bwd_reg_kernel<36, 2, true>), dim3(grid_for((long)B * HW / 2)), dim3(kThreads), 0, s, x, weight, gy, mean,
