@@ -23,9 +23,11 @@ template <> struct Vec<4> {
   static __device__ __forceinline__ T ld(const float* p) { return load4u(p); }
   static __device__ __forceinline__ void st(float* p, T v) { store4u(p, v); }
   static __device__ __forceinline__ float hsum(T v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-  static __device__ __forceinline__ T quad_sum(T v) {
+  template <int LPP> static __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] += __shfl_xor(v[e], 1); v[e] += __shfl_xor(v[e], 2); }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 1; m < LPP; m <<= 1) v[e] += __shfl_xor(v[e], m);
     return v;
   }
 };
@@ -36,9 +38,11 @@ template <> struct Vec<2> {
   static __device__ __forceinline__ T ld(const float* p) { f2u v = *reinterpret_cast<const f2u*>(p); T r = {v.x, v.y}; return r; }
   static __device__ __forceinline__ void st(float* p, T v) { f2u s; s.x = v[0]; s.y = v[1]; *reinterpret_cast<f2u*>(p) = s; }
   static __device__ __forceinline__ float hsum(T v) { return v[0] + v[1]; }
-  static __device__ __forceinline__ T quad_sum(T v) {
+  template <int LPP> static __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { v[e] += __shfl_xor(v[e], 1); v[e] += __shfl_xor(v[e], 2); }
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int m = 1; m < LPP; m <<= 1) v[e] += __shfl_xor(v[e], m);
     return v;
   }
 };
@@ -48,7 +52,11 @@ template <> struct Vec<1> {
   static __device__ __forceinline__ T ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
   static __device__ __forceinline__ float hsum(T v) { return v; }
-  static __device__ __forceinline__ T quad_sum(T v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+  template <int LPP> static __device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+  }
 };
 template <int VEC> __device__ __forceinline__ typename Vec<VEC>::T vrsqrt_eps(typename Vec<VEC>::T v, float invC, float eps);
 template <> __device__ __forceinline__ float vrsqrt_eps<1>(float v, float invC, float eps) { return 1.0f / sqrtf(v * invC + eps); }
@@ -184,23 +192,24 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_kernel(const float* __re
 // lane per pixel column the extra 2C accumulators do not fit (264 / 360 VGPRs when tried), so FOUR adjacent lanes
 // share a pixel vector and each keeps C/4 channels: x-hat, g*w and the accumulators are CQ*VEC + CQ*VEC + 2*CQ
 // registers, and the two channel sums are combined across the quad.  part: [gridDim.x][2C] = (dw | db) per block.
-template <int CQ, int VEC>
+template <int CQ, int VEC, int LPP>      // LPP lanes per pixel vector (4 or 8), CQ = C / LPP channels per lane
 __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ gy, const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, const float* __restrict__ addend,
                                                                      float* __restrict__ gx, float* __restrict__ part, int B, long HW) {
   typedef typename Vec<VEC>::T V;
-  constexpr int C = 4 * CQ;
-  __shared__ float red[(kThreads / 64) * 4 * 2 * CQ];
+  constexpr int C = LPP * CQ;
+  constexpr int LOG = LPP == 8 ? 3 : 2;
+  __shared__ float red[(kThreads / 64) * LPP * 2 * CQ];
   const long nq = HW / VEC;
   const long total = (long)B * nq;
   const float invC = 1.0f / (float)C;
-  const int q = threadIdx.x & 3;
+  const int q = threadIdx.x & (LPP - 1);
   const float* wq = w + q * CQ;
   float aw[CQ], ab[CQ];
 #pragma unroll
   for (int c = 0; c < CQ; ++c) { aw[c] = 0.f; ab[c] = 0.f; }
-  for (long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 2; it < total; it += ((long)gridDim.x * blockDim.x) >> 2) {
+  for (long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> LOG; it < total; it += ((long)gridDim.x * blockDim.x) >> LOG) {
     const long b = it / nq, p = (it - b * nq) * VEC;
     const long base = (b * C + (long)q * CQ) * HW + p;
     const float* xb = x + base;
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float
       s1 += gw[c];
       s2 += gw[c] * xh[c];
     }
-    s1 = Vec<VEC>::quad_sum(s1) * invC;
-    s2 = Vec<VEC>::quad_sum(s2) * invC;
+    s1 = Vec<VEC>::template group_sum<LPP>(s1) * invC;
+    s2 = Vec<VEC>::template group_sum<LPP>(s2) * invC;
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
       V o = rs * (gw[c] - s1 - xh[c] * s2);
@@ -235,15 +244,16 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float
   for (int c = 0; c < CQ; ++c) {
     float a = aw[c], d = ab[c];
 #pragma unroll
-    for (int m = 4; m < 64; m <<= 1) { a += __shfl_xor(a, m); d += __shfl_xor(d, m); }
-    if (lane < 4) { red[(wave * 4 + q) * 2 * CQ + c] = a; red[(wave * 4 + q) * 2 * CQ + CQ + c] = d; }
+    for (int m = LPP; m < 64; m <<= 1) { a += __shfl_xor(a, m); d += __shfl_xor(d, m); }
+    if (lane < LPP) { red[(wave * LPP + q) * 2 * CQ + c] = a; red[(wave * LPP + q) * 2 * CQ + CQ + c] = d; }
   }
   __syncthreads();
+  constexpr int WS = LPP * 2 * CQ;                          // floats per wave in red
   for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
     const int which = i / C, ch = i - which * C;           // 0: dw, 1: db
     const int qq = ch / CQ, k = ch - qq * CQ;
     const int o = qq * 2 * CQ + which * CQ + k;
-    part[(long)blockIdx.x * 2 * C + i] = (red[o] + red[8 * CQ + o]) + (red[16 * CQ + o] + red[24 * CQ + o]);
+    part[(long)blockIdx.x * 2 * C + i] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
   }
 }
 
@@ -433,14 +443,18 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
   static const bool env_read = (g_ln_unfused = std::getenv("CIDNET_LN_UNFUSED") != nullptr, true);
   (void)env_read;
   hipStream_t s = (hipStream_t)stream;
-  if (gx && ((C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0)) && ws_floats >= 2L * C * kFusedBlocks && !g_ln_unfused) {
-    const long lanes = (C == 36 ? (long)B * HW / 4 : (long)B * HW / 2) * 4;
+  if (gx && ((C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0) || (C == 144 && (long)B * HW <= (1L << 18))) &&
+      ws_floats >= 2L * C * kFusedBlocks && !g_ln_unfused) {
+    const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 2 : (long)B * HW * 8);
     const int nblk = (int)((lanes + kThreads - 1) / kThreads < kFusedBlocks ? (lanes + kThreads - 1) / kThreads : kFusedBlocks);
     if (C == 36)
-      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx, ws,
-                         B, HW);
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 4, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
+                         ws, B, HW);
+    else if (C == 72)
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
+                         ws, B, HW);
     else
-      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 1, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
                          ws, B, HW);
     CIDNET_LAUNCH_STATUS();
     hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb);
