@@ -150,6 +150,43 @@ def test_cidnet_config1_400x600(golden, dev):
     assert abs((yd ** 2).sum().item() - s[2]) <= 1e-5 * s[2]
 
 
+def test_cidnet_full_size_batch_properties(dev):
+    """BASELINE.json configs[1] size (400x600, full width): size-independent properties that hold for the reference
+    because nothing in CIDNet mixes samples (per-pixel LayerNorm, per-sample attention, shared PReLU slope):
+    (1) a sample's output does not depend on its batch; (2) the gradient of a summed loss over a batch is the sum of
+    the per-sample gradients.  Exercises every kernel's full-size tiling (partial tiles, W % 4 != 0 levels, split-K,
+    multi-round grids) where the golden fixtures only cover reduced sizes."""
+    import hvi_cidnet_amd as P
+    m = P.CIDNet()
+    load(m, O.make_params(7))
+    m.to(dev)
+    m.two_streams = True
+    x = O.synthetic_batch(91, (8, 3, 400, 600)).to(dev)
+    with torch.no_grad():
+        y8 = m(x)
+        for i in (0, 5):
+            yi = m(x[i:i + 1].contiguous())
+            d = (y8[i:i + 1] - yi).abs().max().item()
+            assert d <= 2e-6, f"sample {i}: batch-of-8 output differs from single-sample output by {d:.3e}"
+    gt = O.synthetic_batch(92, (2, 3, 400, 600)).to(dev)
+
+    def grads(xs, gs):
+        for p in m.parameters():
+            p.grad = None
+        (m(xs) - gs).abs().sum().backward()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    g_ab = grads(x[:2].contiguous(), gt)
+    g_a = grads(x[0:1].contiguous(), gt[0:1].contiguous())
+    g_b = grads(x[1:2].contiguous(), gt[1:2].contiguous())
+    assert len(g_ab) == 191 - 13                                   # I_LCA5.* stays dead at every size
+    for n, g in g_ab.items():
+        ref = g_a[n].double() + g_b[n].double()
+        d = (g.double() - ref).abs().max().item()
+        tol = 2e-4 * ref.abs().max().item() + 1e-6
+        assert d <= tol, f"d{n}: batch gradient differs from the sum of per-sample gradients by {d:.3e} > {tol:.3e}"
+
+
 def test_module_surface(dev):
     import hvi_cidnet_amd as P
     m = P.CIDNet().to(dev)
