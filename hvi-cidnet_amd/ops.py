@@ -541,14 +541,14 @@ class UpFn(torch.autograd.Function):
         go = _c(go)
         dpre, dslope = prelu_bwd(go, pre, slope)
         g_wup = grad_like(w_up)
-        pw_wgrad(dpre, 0, Co * HWh, skip, 0, Co * HWh, g_wup, Co, 2 * Co, B, Co, Co, HWh)
+        _offload_wgrad((dpre, skip, g_wup), lambda: pw_wgrad(dpre, 0, Co * HWh, skip, 0, Co * HWh, g_wup, Co, 2 * Co, B, Co, Co, HWh))
         dskip = None
         if ctx.needs_input_grad[1]:
             dskip = torch.empty_like(skip)
             pw_conv(dpre, 0, Co * HWh, w_up, Co, 0, 1, 2 * Co, dskip, 0, Co * HWh, B, Co, Co, HWh)
         dz = torch.empty_like(t)
         bilinear_bwd(dpre, dz, B, Co, h, wd, 2 * h, 2 * wd)
-        pw_wgrad(dz, 0, Co * HWl, t, 0, Co * HWl, g_wup, 0, 2 * Co, B, Co, Co, HWl)
+        _offload_wgrad((dz, t, g_wup), lambda: pw_wgrad(dz, 0, Co * HWl, t, 0, Co * HWl, g_wup, 0, 2 * Co, B, Co, Co, HWl))
         dt = torch.empty_like(t)
         pw_conv(dz, 0, Co * HWl, w_up, 0, 0, 1, 2 * Co, dt, 0, Co * HWl, B, Co, Co, HWl)
         gw = grad_like(w)
