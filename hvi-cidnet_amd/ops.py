@@ -661,6 +661,37 @@ class L1LossFn(torch.autograd.Function):
         return grad * g, None        # g is the scalar d(total)/d(loss); 1.0 in the benchmark step
 
 
+class SSIMLossFn(torch.autograd.Function):
+    """(1 - mean(ssim_map(img1, img2))) * weight: reference SSIM.forward (loss/losses.py:166-190) with map_ssim
+    (loss/loss_utils.py:125-145); 11x11 Gaussian window, zero padding.  Gradient to img1 only (img2 = ground truth)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, weight):
+        _check(img1, img2)
+        img1, img2 = _c(img1), _c(img2)
+        if img1.shape != img2.shape or img1.dim() != 4:
+            raise RuntimeError("SSIM: img1 and img2 must be (B,C,H,W) tensors of the same shape")
+        B, C, H, W = img1.shape
+        dA, dB, dC = torch.empty_like(img1), torch.empty_like(img1), torch.empty_like(img1)
+        loss = torch.empty((), device=img1.device, dtype=torch.float32)
+        n = _raw("cidnet_ssim_ws_floats", B, C, H, W)
+        ws = _ws(n, img1.device)
+        lib().call("cidnet_ssim_fwd", _p(img1), _p(img2), _f(weight), _p(loss), _p(dA), _p(dB), _p(dC), _p(ws), ws.numel(), B, C, H, W,
+                   _stream())
+        ctx.save_for_backward(img1, img2, dA, dB, dC)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        img1, img2, dA, dB, dC = ctx.saved_tensors
+        B, C, H, W = img1.shape
+        g = g.to(torch.float32).reshape(1).contiguous()
+        gx = torch.empty_like(img1)
+        lib().call("cidnet_ssim_bwd", _p(img1), _p(img2), _p(dA), _p(dB), _p(dC), _p(g), _f(ctx.weight), _p(gx), B, C, H, W, _stream())
+        return gx, None, None
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _check(p, g, m, v)
     lib().call("cidnet_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _f(lr), _f(beta1), _f(beta2), _f(eps),

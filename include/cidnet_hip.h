@@ -182,6 +182,15 @@ int cidnet_sum_rows(const float* in, int n_red, long n, float* out, void* stream
 long cidnet_l1_loss_ws_floats(void);
 int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, float* ws,
                    long ws_floats, long n, void* stream);
+/* SSIM loss ("next" row f1): SSIM.forward, loss/losses.py:166-190 with map_ssim, loss/loss_utils.py:125-145:
+ * 11x11 Gaussian window (sigma 1.5), zero padding 5, depthwise; loss = (1 - mean(ssim_map)) * weight (1 float on the
+ * device).  dA/dB/dC (B,C,H,W each) are the per-pixel derivative maps the backward filters; ws: block partials.
+ * The backward gives d(total)/d(img1) for a device scalar gloss = d(total)/d(loss); img2 (the ground truth) gets none. */
+long cidnet_ssim_ws_floats(int B, int C, int H, int W);
+int cidnet_ssim_fwd(const float* img1, const float* img2, float weight, float* loss, float* dA, float* dB,
+                    float* dC, float* ws, long ws_floats, int B, int C, int H, int W, void* stream);
+int cidnet_ssim_bwd(const float* img1, const float* img2, const float* dA, const float* dB, const float* dC,
+                    const float* gloss, float weight, float* gimg1, int B, int C, int H, int W, void* stream);
 /* torch.optim.Adam step (train.py:166) over one flat buffer; g is multiplied by grad_scale first
  * (1/world_size after a sum all-reduce).  step = 1-based update count. */
 int cidnet_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,

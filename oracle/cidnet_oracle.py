@@ -337,6 +337,39 @@ def spatial_attention(x, w):
 
 
 # --------------------------------------------------------------------------------------
+# training losses ("next" row f1)
+# --------------------------------------------------------------------------------------
+def ssim_window(window_size: int = 11, sigma: float = 1.5, channel: int = 3) -> torch.Tensor:
+    """`create_window` / `gaussian`, loss/loss_utils.py:113-123: normalised Gaussian, outer product, one copy per channel."""
+    import math
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)],
+                     dtype=torch.float32)
+    g = (g / torch.sum(g)).unsqueeze(1)
+    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous()
+
+
+def ssim_map(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
+    """`map_ssim` before its mean, loss/loss_utils.py:125-140 (depthwise Gaussian filtering with zero padding)."""
+    c = img1.shape[1]
+    w = ssim_window(window_size, 1.5, c).to(img1.dtype)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, w, padding=pad, groups=c)
+    mu2 = F.conv2d(img2, w, padding=pad, groups=c)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(img1 * img1, w, padding=pad, groups=c) - mu1_sq
+    s2 = F.conv2d(img2 * img2, w, padding=pad, groups=c) - mu2_sq
+    s12 = F.conv2d(img1 * img2, w, padding=pad, groups=c) - mu1_mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu1_mu2 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
+
+
+def ssim_loss(img1: torch.Tensor, img2: torch.Tensor, weight: float = 1.0, window_size: int = 11) -> torch.Tensor:
+    """`SSIM.forward`, loss/losses.py:166-190 (size_average=True): (1 - mean(ssim_map)) * weight."""
+    return (1.0 - ssim_map(img1, img2, window_size).mean()) * weight
+
+
+# --------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------
 def cidnet_forward(p: Params, x: torch.Tensor, heads=(1, 2, 4, 8), this_k: Optional[float] = None,

@@ -491,6 +491,34 @@ def gen_tnsm():
     print("wrote tnsm.npz", len(out), "arrays")
 
 
+def gen_losses():
+    """SSIM training loss ("next" row f1).  loss.loss_utils (map_ssim, create_window) imports here; loss.losses does not
+    (it imports torchvision for the VGG loss), so the SSIM class's one line of arithmetic around map_ssim,
+    (1 - map_ssim(...)) * weight (loss/losses.py:189), is applied to the reference's map_ssim output."""
+    from loss.loss_utils import map_ssim, create_window
+    out = {}
+    for tag, shape in (("a", (2, 3, 40, 52)), ("b", (1, 3, 33, 71)), ("c", (2, 1, 12, 9))):
+        x = O.synthetic_batch(101, shape)
+        y = (0.7 * x + 0.3 * O.synthetic_batch(102, shape)).clamp(0, 1)
+        if tag == "b":
+            y[..., :9, :] = 0.0                                  # a flat black band: sigma terms vanish there
+        c = shape[1]
+        for weight in (1.0, 0.5):
+            xr = x.clone().requires_grad_(True)
+            lr = (1.0 - map_ssim(xr, y, create_window(11, c), 11, c, True)) * weight
+            lr.backward()
+            xo = x.clone().requires_grad_(True)
+            lo = O.ssim_loss(xo, y, weight)
+            lo.backward()
+            check_equal(lo, lr, f"SSIM loss {tag} w={weight}", exact=False, tol=1e-7)
+            check_equal(xo.grad, xr.grad, f"SSIM grad {tag} w={weight}", exact=False, tol=1e-6)
+            out[f"{tag}_w{weight}_loss"] = np.float64(lr.item())
+            out[f"{tag}_w{weight}_grad"] = xr.grad.numpy()
+        out[f"{tag}_x"], out[f"{tag}_y"] = x.numpy(), y.numpy()
+    np.savez_compressed(os.path.join(GOLD, "losses.npz"), **out)
+    print("wrote losses.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mssa":
         gen_mssa()
@@ -498,10 +526,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tnsm":
         gen_tnsm()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":
+        gen_losses()
+        sys.exit(0)
     gen_hvi()
     gen_blocks()
     gen_model()
     gen_mssa()
     gen_tnsm()
+    gen_losses()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

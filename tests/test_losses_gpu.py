@@ -1,0 +1,64 @@
+"""GPU parity of the device-side training losses ("next" row f1): SSIM (and L1) against the reference's own values and
+gradients in tests/golden/losses.npz (written by oracle/gen_golden.py from loss/loss_utils.map_ssim), against the oracle
+on seeded full-size inputs, and the combined RGB + HVI objective against the oracle's composition."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cidnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("weight", [1.0, 0.5])
+def test_ssim_golden(golden, dev, tag, weight):
+    import hvi_cidnet_amd as P
+    g = golden("losses")
+    x = torch.from_numpy(g[f"{tag}_x"]).to(dev).requires_grad_(True)
+    y = torch.from_numpy(g[f"{tag}_y"]).to(dev)
+    loss = P.SSIM(weight=weight)(x, y)
+    loss.backward()
+    ref_l, ref_g = float(g[f"{tag}_w{weight}_loss"]), torch.from_numpy(g[f"{tag}_w{weight}_grad"])
+    assert abs(loss.item() - ref_l) <= 2e-6, (loss.item(), ref_l)
+    d = (x.grad.cpu() - ref_g).abs().max().item()
+    assert d <= 1e-4 * ref_g.abs().max().item() + 1e-9, f"SSIM grad: {d:.3e} vs max {ref_g.abs().max().item():.3e}"
+
+
+def test_ssim_full_size_vs_oracle(dev):
+    """8x3x400x600 (the benchmark's image size): value against the fp64 oracle, gradient on one sample, upstream scale"""
+    import hvi_cidnet_amd as P
+    x = O.synthetic_batch(111, (8, 3, 400, 600))
+    y = (0.8 * x + 0.2 * O.synthetic_batch(112, (8, 3, 400, 600))).clamp(0, 1)
+    xd = x.to(dev).requires_grad_(True)
+    loss = P.SSIM(weight=0.5)(xd, y.to(dev))
+    (3.0 * loss).backward()
+    ref = O.ssim_loss(x.double(), y.double(), 0.5)
+    assert abs(loss.item() - ref.item()) <= 2e-6
+    xs = x[:1].double().requires_grad_(True)
+    (3.0 * O.ssim_loss(xs, y[:1].double(), 0.5) / 8.0).backward()      # a sample's share of the batch mean
+    d = (xd.grad[:1].cpu().double() - xs.grad).abs().max().item()
+    assert d <= 1e-4 * xs.grad.abs().max().item() + 1e-10, d
+
+
+def test_cidnet_loss_composition(dev):
+    """loss_rgb + HVI_weight * loss_hvi with L1 + SSIM terms (train.py:61-65 minus Edge / perceptual) == oracle composition,
+    and its gradient reaches the image through both the RGB terms and the HVIT of the output"""
+    import hvi_cidnet_amd as P
+    m = P.CIDNet(channels=[12, 12, 24, 48]).to(dev)
+    crit = P.CIDNetLoss(m, L1_weight=1.0, D_weight=0.5, HVI_weight=1.0)
+    out = O.synthetic_batch(121, (2, 3, 32, 48))
+    gt = O.synthetic_batch(122, (2, 3, 32, 48))
+    od = out.to(dev).requires_grad_(True)
+    loss = crit(od, gt.to(dev))
+    loss.backward()
+    k = m.trans.density_k.detach().cpu().double()
+    o64 = out.double().requires_grad_(True)
+    oh, gh = O.hvit(o64, k), O.hvit(gt.double(), k)
+    ref = ((o64 - gt.double()).abs().mean() + O.ssim_loss(o64, gt.double(), 0.5)) + 1.0 * ((oh - gh).abs().mean() + O.ssim_loss(oh, gh, 0.5))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 5e-6, (loss.item(), ref.item())
+    d = (od.grad.cpu().double() - o64.grad).abs()
+    # |.| kinks of the L1 terms and the hue branch cuts of HVIT: compare where the two gradients can agree
+    ok = d <= 2e-4 * o64.grad.abs().max().item() + 1e-9
+    assert ok.double().mean().item() > 0.995, f"only {ok.double().mean().item():.4f} of the gradient entries agree"

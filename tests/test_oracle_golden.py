@@ -126,3 +126,18 @@ def test_tnsm_matches_reference(golden):
             assert v.grad is None
         else:
             _close(v.grad, g[f"model_g.{n}"], rel=1e-5)
+
+
+def test_ssim_oracle_matches_reference_fixture(golden):
+    """oracle.ssim_loss reproduces the reference's map_ssim-based SSIM loss and its gradient (tests/golden/losses.npz)"""
+    import torch
+    g = golden("losses")
+    for tag in ("a", "b", "c"):
+        for weight in (1.0, 0.5):
+            x = torch.from_numpy(g[f"{tag}_x"]).requires_grad_(True)
+            y = torch.from_numpy(g[f"{tag}_y"])
+            loss = O.ssim_loss(x, y, weight)
+            loss.backward()
+            assert abs(loss.item() - float(g[f"{tag}_w{weight}_loss"])) <= 1e-7
+            ref = torch.from_numpy(g[f"{tag}_w{weight}_grad"])
+            assert (x.grad - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-12
