@@ -212,6 +212,12 @@ class DataParallelTrainer:
             self._handles.append(dist.all_reduce(self.flat_g[start:start + cnt], op=dist.ReduceOp.SUM, group=self.pg,
                                                  async_op=True))
 
+    def set_lr(self, lr: float):
+        """learning rate of the fused Adam from the next step on (see schedule.WarmupCosineLR)"""
+        self._opt_args["lr"] = float(lr)
+        if getattr(self, "opt", None) is not None:
+            self.opt.lr = float(lr)
+
     # ---- hipGraph replay of forward + loss + backward ---------------------------------------------
     def _fwd_bwd(self, x, gt):
         for bi, (_, _, mem) in enumerate(self.buckets):

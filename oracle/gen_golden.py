@@ -519,6 +519,34 @@ def gen_losses():
     print("wrote losses.npz", len(out), "arrays")
 
 
+def gen_lr_schedule():
+    """Learning-rate sequences of the reference's own scheduler classes (data/scheduler.py) as train.py builds them."""
+    from data.scheduler import GradualWarmupScheduler, CosineAnnealingRestartLR
+    import warnings
+    out = {}
+    for tag, (lr, n_ep, warm, start, use_warm) in {"default": (1e-4, 1000, 3, 0, True), "short": (2e-4, 20, 3, 0, True),
+                                                   "nowarm": (1e-4, 30, 3, 0, False), "resume": (1e-4, 50, 2, 10, True)}.items():
+        prm = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([prm], lr=lr)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if use_warm:
+                inner = CosineAnnealingRestartLR(optimizer=opt, periods=[n_ep - warm - start], restart_weights=[1], eta_min=1e-7)
+                sch = GradualWarmupScheduler(opt, multiplier=1, total_epoch=warm, after_scheduler=inner)
+            else:
+                sch = CosineAnnealingRestartLR(optimizer=opt, periods=[n_ep - start], restart_weights=[1], eta_min=1e-7)
+            seq = [opt.param_groups[0]["lr"]]
+            for _ in range(n_ep - start):
+                opt.step()
+                sch.step()
+                seq.append(opt.param_groups[0]["lr"])
+        out[tag + "_cfg"] = np.array([lr, n_ep, warm, start, float(use_warm)])
+        out[tag + "_lr"] = np.array(seq, dtype=np.float64)
+        print(f"  {tag}: lr[0..5] = {seq[:6]}, last = {seq[-1]:.3e}")
+    np.savez_compressed(os.path.join(GOLD, "lr_schedule.npz"), **out)
+    print("wrote lr_schedule.npz")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mssa":
         gen_mssa()
@@ -529,11 +557,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         gen_losses()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lr":
+        gen_lr_schedule()
+        sys.exit(0)
     gen_hvi()
     gen_blocks()
     gen_model()
     gen_mssa()
     gen_tnsm()
     gen_losses()
+    gen_lr_schedule()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

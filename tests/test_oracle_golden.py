@@ -141,3 +141,16 @@ def test_ssim_oracle_matches_reference_fixture(golden):
             assert abs(loss.item() - float(g[f"{tag}_w{weight}_loss"])) <= 1e-7
             ref = torch.from_numpy(g[f"{tag}_w{weight}_grad"])
             assert (x.grad - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("tag", ["default", "short", "nowarm", "resume"])
+def test_lr_schedule_matches_reference_sequence(golden, tag):
+    """schedule.WarmupCosineLR ("next" row f2) reproduces the learning rates the reference's own scheduler classes set,
+    step by step (tests/golden/lr_schedule.npz was written by stepping data/scheduler.py as train.py:165-181 builds it)"""
+    from hvi_cidnet_amd.schedule import WarmupCosineLR
+    g = golden("lr_schedule")
+    lr, n_ep, warm, start, use_warm = g[tag + "_cfg"]
+    sch = WarmupCosineLR(lr, int(n_ep), int(warm), int(start), bool(use_warm))
+    ref = g[tag + "_lr"]
+    got = np.array([sch.lr_after(n) for n in range(len(ref))])
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-18), np.abs(got - ref).max()
