@@ -14,6 +14,6 @@ from .tnsm import HV_TNSM, I_TNSM, TrainableNoiseSuppression
 from .hvi_transform import RGB_HVI
 from .lca import CAB, IEL, HV_LCA, I_LCA
 from .transformer_utils import LayerNorm, NormDownsample, NormUpsample
-from .losses import L1Loss, SSIM, CIDNetLoss
+from .losses import L1Loss, SSIM, EdgeLoss, CIDNetLoss
 
-__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "CIDNetLoss"]
+__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "EdgeLoss", "CIDNetLoss"]

@@ -1,7 +1,7 @@
 """Training losses on device ("next" row f1 of SURVEY section 8): drop-ins for the reference's `L1Loss` and `SSIM`
-(loss/losses.py:10-38, 166-190) with the same constructor arguments.  EdgeLoss (losses.py:41-65) and the VGG19
-PerceptualLoss (:68-161, needs downloaded weights) are not built yet; `CIDNetLoss` is the reference's training
-objective (train.py:61-65) restricted to the two built terms."""
+(loss/losses.py:10-38, 166-190) and `EdgeLoss` (:41-65) with the same constructor arguments.  The VGG19
+PerceptualLoss (:68-161) needs downloaded weights and is not built; `CIDNetLoss` is the reference's training objective
+(train.py:61-65) without that term."""
 import torch.nn as nn
 
 from . import ops
@@ -39,19 +39,34 @@ class SSIM(nn.Module):
         return ops.SSIMLossFn.apply(img1, img2, float(self.weight))
 
 
-class CIDNetLoss(nn.Module):
-    """loss_rgb + HVI_weight * loss_hvi with loss_* = L1 + SSIM (train.py:61-65 without the Edge / perceptual terms):
-    `model` supplies HVIT for the HVI-space terms, exactly as train.py calls `model.HVIT` on output and ground truth."""
+class EdgeLoss(nn.Module):
+    """Laplacian-pyramid edge loss: mse(laplacian(x), laplacian(y)) * loss_weight (5x5 blur, replicate padding)."""
 
-    def __init__(self, model, L1_weight=1.0, D_weight=0.5, HVI_weight=1.0):
+    def __init__(self, loss_weight=1.0, reduction="mean"):
+        super().__init__()
+        self.weight = loss_weight
+
+    def forward(self, x, y):
+        return ops.EdgeLossFn.apply(x, y, float(self.weight))
+
+
+class CIDNetLoss(nn.Module):
+    """loss_rgb + HVI_weight * loss_hvi with loss_* = L1 + SSIM + Edge (train.py:61-65 without the perceptual term);
+    defaults are data/options.py:56-59.  `model` supplies HVIT for the HVI-space terms, exactly as train.py calls
+    `model.HVIT` on the output and on the ground truth."""
+
+    def __init__(self, model, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0):
         super().__init__()
         self.l1 = L1Loss(loss_weight=L1_weight)
         self.ssim = SSIM(weight=D_weight)
+        self.edge = EdgeLoss(loss_weight=E_weight)
         self.hvi_weight = HVI_weight
         self._hvit = model.HVIT
 
+    def _terms(self, a, b):
+        return self.l1(a, b) + self.ssim(a, b) + self.edge(a, b)
+
     def forward(self, output_rgb, gt_rgb):
-        out_hvi, gt_hvi = self._hvit(output_rgb), self._hvit(gt_rgb)
-        loss_hvi = self.l1(out_hvi, gt_hvi) + self.ssim(out_hvi, gt_hvi)
-        loss_rgb = self.l1(output_rgb, gt_rgb) + self.ssim(output_rgb, gt_rgb)
+        loss_hvi = self._terms(self._hvit(output_rgb), self._hvit(gt_rgb))
+        loss_rgb = self._terms(output_rgb, gt_rgb)
         return loss_rgb + self.hvi_weight * loss_hvi

@@ -692,6 +692,37 @@ class SSIMLossFn(torch.autograd.Function):
         return gx, None, None
 
 
+class EdgeLossFn(torch.autograd.Function):
+    """mean((laplacian(x) - laplacian(y))^2) * weight: reference EdgeLoss.forward (loss/losses.py:41-65).  Gradient to x only."""
+
+    @staticmethod
+    def forward(ctx, x, y, weight):
+        _check(x, y)
+        x, y = _c(x), _c(y)
+        if x.shape != y.shape or x.dim() != 4:
+            raise RuntimeError("EdgeLoss: x and y must be (B,C,H,W) tensors of the same shape")
+        B, C, H, W = x.shape
+        lap = torch.empty_like(x)
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        n = _raw("cidnet_edge_ws_floats", B, C, H, W)
+        ws = _ws(n, x.device)
+        lib().call("cidnet_edge_fwd", _p(x), _p(y), _f(weight), _p(loss), _p(lap), _p(ws), ws.numel(), B, C, H, W, _stream())
+        ctx.save_for_backward(lap)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (lap,) = ctx.saved_tensors
+        B, C, H, W = lap.shape
+        g = g.to(torch.float32).reshape(1).contiguous()
+        gx = torch.empty_like(lap)
+        n = _raw("cidnet_edge_ws_floats", B, C, H, W)
+        ws = _ws(n, lap.device)
+        lib().call("cidnet_edge_bwd", _p(lap), _p(g), _f(ctx.weight), _p(gx), _p(ws), ws.numel(), B, C, H, W, _stream())
+        return gx, None, None
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _check(p, g, m, v)
     lib().call("cidnet_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _f(lr), _f(beta1), _f(beta2), _f(eps),

@@ -191,6 +191,15 @@ int cidnet_ssim_fwd(const float* img1, const float* img2, float weight, float* l
                     float* dC, float* ws, long ws_floats, int B, int C, int H, int W, void* stream);
 int cidnet_ssim_bwd(const float* img1, const float* img2, const float* dA, const float* dB, const float* dC,
                     const float* gloss, float weight, float* gimg1, int B, int C, int H, int W, void* stream);
+/* EdgeLoss ("next" row f1): EdgeLoss.forward, loss/losses.py:41-65: laplacian(z) = z - G(U(G(z))) with G the 5x5
+ * replicate-padded blur outer([.05 .25 .4 .25 .05]) and U = even pixels x4; loss = mean((lap(x) - lap(y))^2) * weight.
+ * fwd saves lap = laplacian(x - y) (B,C,H,W); bwd gives d(total)/dx = gloss * 2 weight / n * (lap - G^T U G^T lap).
+ * ws: B*C*H*W + 2048 floats. */
+long cidnet_edge_ws_floats(int B, int C, int H, int W);
+int cidnet_edge_fwd(const float* x, const float* y, float weight, float* loss, float* lap, float* ws,
+                    long ws_floats, int B, int C, int H, int W, void* stream);
+int cidnet_edge_bwd(const float* lap, const float* gloss, float weight, float* gx, float* ws, long ws_floats,
+                    int B, int C, int H, int W, void* stream);
 /* torch.optim.Adam step (train.py:166) over one flat buffer; g is multiplied by grad_scale first
  * (1/world_size after a sum all-reduce).  step = 1-based update count. */
 int cidnet_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,

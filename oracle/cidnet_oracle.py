@@ -369,6 +369,29 @@ def ssim_loss(img1: torch.Tensor, img2: torch.Tensor, weight: float = 1.0, windo
     return (1.0 - ssim_map(img1, img2, window_size).mean()) * weight
 
 
+def edge_laplacian(img: torch.Tensor) -> torch.Tensor:
+    """`EdgeLoss.laplacian_kernel`, loss/losses.py:52-59 (with `conv_gauss`, :47-50): 5x5 blur outer([.05,.25,.4,.25,.05]),
+    replicate padding, depthwise; blur -> keep even pixels x4 (zeros elsewhere) -> blur; current - that.
+    RESTATED FROM THE TEXT, parity unpinned: loss.losses cannot be imported here (it imports torchvision for the VGG
+    loss) and EdgeLoss.__init__ hard-codes .cuda(); only its reduction (`mse_loss`) is importable from loss_utils."""
+    c = img.shape[1]
+    k = torch.tensor([[.05, .25, .4, .25, .05]], dtype=torch.float32)
+    kern = torch.matmul(k.t(), k).unsqueeze(0).repeat(c, 1, 1, 1).to(img.dtype)
+
+    def conv_gauss(t):
+        return F.conv2d(F.pad(t, (2, 2, 2, 2), mode="replicate"), kern, groups=c)
+
+    filtered = conv_gauss(img)
+    new_filter = torch.zeros_like(filtered)
+    new_filter[:, :, ::2, ::2] = filtered[:, :, ::2, ::2] * 4
+    return img - conv_gauss(new_filter)
+
+
+def edge_loss(x: torch.Tensor, y: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+    """`EdgeLoss.forward`, loss/losses.py:61-63: mse_loss(laplacian(x), laplacian(y)) (mean) * weight."""
+    return F.mse_loss(edge_laplacian(x), edge_laplacian(y)) * weight
+
+
 # --------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------

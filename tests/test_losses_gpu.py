@@ -41,12 +41,41 @@ def test_ssim_full_size_vs_oracle(dev):
     assert d <= 1e-4 * xs.grad.abs().max().item() + 1e-10, d
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 40, 52), (1, 3, 33, 71), (2, 1, 7, 5), (1, 3, 2, 9)])
+def test_edge_loss_vs_oracle(dev, shape):
+    """EdgeLoss value and gradient against the fp64 oracle (even / odd sizes: the x4 up-sampling grid and the
+    replicate-padding adjoint at all four borders; planes smaller than the 5x5 window)"""
+    import hvi_cidnet_amd as P
+    x = O.synthetic_batch(131, shape)
+    y = (0.6 * x + 0.4 * O.synthetic_batch(132, shape)).clamp(0, 1)
+    xd = x.to(dev).requires_grad_(True)
+    loss = P.EdgeLoss(loss_weight=50.0)(xd, y.to(dev))
+    (0.5 * loss).backward()
+    x64 = x.double().requires_grad_(True)
+    ref = O.edge_loss(x64, y.double(), 50.0)
+    (0.5 * ref).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-9, (loss.item(), ref.item())
+    d = (xd.grad.cpu().double() - x64.grad).abs().max().item()
+    assert d <= 1e-4 * x64.grad.abs().max().item() + 1e-12, d
+
+
+def test_edge_loss_full_size(dev):
+    import hvi_cidnet_amd as P
+    x = O.synthetic_batch(133, (8, 3, 400, 600))
+    y = O.synthetic_batch(134, (8, 3, 400, 600))
+    loss = P.EdgeLoss(loss_weight=50.0)(x.to(dev), y.to(dev))
+    ref = O.edge_loss(x[:2].double(), y[:2].double(), 50.0)            # the loss is a mean: compare a 2-sample sub-batch
+    sub = P.EdgeLoss(loss_weight=50.0)(x[:2].to(dev), y[:2].to(dev))
+    assert abs(sub.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert loss.item() > 0
+
+
 def test_cidnet_loss_composition(dev):
-    """loss_rgb + HVI_weight * loss_hvi with L1 + SSIM terms (train.py:61-65 minus Edge / perceptual) == oracle composition,
+    """loss_rgb + HVI_weight * loss_hvi with L1 + SSIM + Edge terms (train.py:61-65 minus the perceptual one) == oracle composition,
     and its gradient reaches the image through both the RGB terms and the HVIT of the output"""
     import hvi_cidnet_amd as P
     m = P.CIDNet(channels=[12, 12, 24, 48]).to(dev)
-    crit = P.CIDNetLoss(m, L1_weight=1.0, D_weight=0.5, HVI_weight=1.0)
+    crit = P.CIDNetLoss(m, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0)
     out = O.synthetic_batch(121, (2, 3, 32, 48))
     gt = O.synthetic_batch(122, (2, 3, 32, 48))
     od = out.to(dev).requires_grad_(True)
@@ -55,9 +84,10 @@ def test_cidnet_loss_composition(dev):
     k = m.trans.density_k.detach().cpu().double()
     o64 = out.double().requires_grad_(True)
     oh, gh = O.hvit(o64, k), O.hvit(gt.double(), k)
-    ref = ((o64 - gt.double()).abs().mean() + O.ssim_loss(o64, gt.double(), 0.5)) + 1.0 * ((oh - gh).abs().mean() + O.ssim_loss(oh, gh, 0.5))
+    ref = ((o64 - gt.double()).abs().mean() + O.ssim_loss(o64, gt.double(), 0.5) + O.edge_loss(o64, gt.double(), 50.0)) + \
+        1.0 * ((oh - gh).abs().mean() + O.ssim_loss(oh, gh, 0.5) + O.edge_loss(oh, gh, 50.0))
     ref.backward()
-    assert abs(loss.item() - ref.item()) <= 5e-6, (loss.item(), ref.item())
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 5e-6, (loss.item(), ref.item())
     d = (od.grad.cpu().double() - o64.grad).abs()
     # |.| kinks of the L1 terms and the hue branch cuts of HVIT: compare where the two gradients can agree
     ok = d <= 2e-4 * o64.grad.abs().max().item() + 1e-9

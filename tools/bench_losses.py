@@ -1,4 +1,4 @@
-"""Cost of the device-side training objective (L1 + SSIM on RGB and on HVIT(out)) at the benchmark's image size (dev tool)."""
+"""Cost of the device-side training objective (L1 + SSIM + Edge on RGB and on HVIT(out)) at the benchmark's image size (dev tool)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,4 +21,4 @@ def f_ssim():
     out.grad = None; ssim(out, gt).backward()
 def f_all():
     out.grad = None; crit(out, gt).backward()
-print(json.dumps({"shape": "8x3x400x600", "ssim_fwd_bwd_ms": round(timeit(f_ssim), 3), "l1+ssim_rgb_and_hvi_fwd_bwd_ms": round(timeit(f_all), 3)}))
+print(json.dumps({"shape": "8x3x400x600", "ssim_fwd_bwd_ms": round(timeit(f_ssim), 3), "l1+ssim+edge_rgb_and_hvi_fwd_bwd_ms": round(timeit(f_all), 3)}))
