@@ -15,5 +15,8 @@ from .hvi_transform import RGB_HVI
 from .lca import CAB, IEL, HV_LCA, I_LCA
 from .transformer_utils import LayerNorm, NormDownsample, NormUpsample
 from .losses import L1Loss, SSIM, EdgeLoss, CIDNetLoss
+from .inference import enhance, load_weights, save_pretrained, pad_to_multiple
+from .schedule import WarmupCosineLR
 
-__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "EdgeLoss", "CIDNetLoss"]
+__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "EdgeLoss", "CIDNetLoss", "enhance", "load_weights", "save_pretrained", "pad_to_multiple",
+           "WarmupCosineLR"]
