@@ -138,3 +138,26 @@ def test_trainer_graph_replay_equals_eager(dev):
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_trainer_with_reference_objective(dev):
+    """the training step driven by the reference's objective (L1 + SSIM + Edge on RGB and on HVIT(out), train.py:61-65
+    without the VGG term): gradients reach every live parameter, including density_k through the loss-side HVIT,
+    and a few steps reduce the loss"""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
+    chans, shape = (12, 12, 24, 48), (2, 3, 32, 48)
+    m = _model(dev, chans)
+    x = O.synthetic_batch(71, shape).to(dev)
+    gt = O.synthetic_batch(72, shape).to(dev)
+    tr = DataParallelTrainer(m, lr=2e-3, n_buckets=3, loss_fn=P.CIDNetLoss(m))
+    losses = [float(tr.step(x, gt).item()) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(l == l for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert tr.flat_g[:tr.n_live].abs().max().item() > 0
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
