@@ -8,6 +8,7 @@
 // cover consecutive 16 B pieces of a row (dense: ceil(W/4) lanes per row, no padding to a power of
 // two), then the next strip.  The strip height is picked per launch (pick_tiling): as tall as the
 // plane count allows, because every strip re-reads its halo rows.  HBM-bound by construction.
+#include <type_traits>
 #include "common.h"
 #include "stencil.h"
 
@@ -205,28 +206,41 @@ __global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const float* __re
     }
     return o;
   };
-  Win8 a0, a1 = load_win8<NARROW>(p1, y0 - 2, x0, H, W), a2 = load_win8<NARROW>(p1, y0 - 1, x0, H, W);
-  Win8 b0, b1 = load_win8<NARROW>(p2, y0 - 2, x0, H, W), b2 = load_win8<NARROW>(p2, y0 - 1, x0, H, W);
-  Win6 ua0, ua1, ub0, ub1;                       // u rows r-2, r-1 of the two channels
+  // Rolling windows live in three slots whose roles (row r-1, r, r+1) rotate with the row phase; the row loop is
+  // unrolled by three so every slot index is a compile-time constant and no register moves are spent on the shift
+  // (they were 17 % of the loop's VALU instructions in a kernel that is VALU-issue-bound).
+  Win8 A[3], Bw[3];
+  Win6 UA[3], UB[3];                             // u rows of the two channels
+  A[1] = load_win8<NARROW>(p1, y0 - 2, x0, H, W); A[2] = load_win8<NARROW>(p1, y0 - 1, x0, H, W);
+  Bw[1] = load_win8<NARROW>(p2, y0 - 2, x0, H, W); Bw[2] = load_win8<NARROW>(p2, y0 - 1, x0, H, W);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { ua0.v[i] = ua1.v[i] = ub0.v[i] = ub1.v[i] = 0.f; }
-  for (int r = y0 - 1; r <= yend; ++r) {
-    a0 = a1; a1 = a2; a2 = load_win8<NARROW>(p1, r + 1, x0, H, W);
-    b0 = b1; b1 = b2; b2 = load_win8<NARROW>(p2, r + 1, x0, H, W);
-    const Win6 ua2 = u_row(a0, a1, a2, wpa, r), ub2 = u_row(b0, b1, b2, wpb, r);
+  for (int i = 0; i < 6; ++i) { UA[1].v[i] = UA[2].v[i] = UB[1].v[i] = UB[2].v[i] = 0.f; }
+  auto step = [&](auto PH, int r) __attribute__((always_inline)) {
+    constexpr int ph = decltype(PH)::value;
+    constexpr int s0 = (ph + 1) % 3, s1 = (ph + 2) % 3, s2 = ph;
+    A[s2] = load_win8<NARROW>(p1, r + 1, x0, H, W);
+    Bw[s2] = load_win8<NARROW>(p2, r + 1, x0, H, W);
+    UA[s2] = u_row(A[s0], A[s1], A[s2], wpa, r);
+    UB[s2] = u_row(Bw[s0], Bw[s1], Bw[s2], wpb, r);
     if (r >= y0 && r < yend) {
-      store_px4<NARROW>(u1, r, x0, W, f32x4{ua2.v[1], ua2.v[2], ua2.v[3], ua2.v[4]});
-      store_px4<NARROW>(u2, r, x0, W, f32x4{ub2.v[1], ub2.v[2], ub2.v[3], ub2.v[4]});
+      store_px4<NARROW>(u1, r, x0, W, f32x4{UA[s2].v[1], UA[s2].v[2], UA[s2].v[3], UA[s2].v[4]});
+      store_px4<NARROW>(u2, r, x0, W, f32x4{UB[s2].v[1], UB[s2].v[2], UB[s2].v[3], UB[s2].v[4]});
     }
     const int q = r - 1;                         // gate row q needs u rows q-1, q, q+1
     if (q >= y0 && q < yend) {
-      const f32x4 c1 = stencil(ua0, ua1, ua2, wa), c2 = stencil(ub0, ub1, ub2, wb);
+      const f32x4 c1 = stencil(UA[s0], UA[s1], UA[s2], wa), c2 = stencil(UB[s0], UB[s1], UB[s2], wb);
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (tanh_fast(c1[e]) + ua1.v[1 + e]) * (tanh_fast(c2[e]) + ub1.v[1 + e]);
+      for (int e = 0; e < 4; ++e) o[e] = (tanh_fast(c1[e]) + UA[s1].v[1 + e]) * (tanh_fast(c2[e]) + UB[s1].v[1 + e]);
       store_px4<NARROW>(gp, q, x0, W, o);
     }
-    ua0 = ua1; ua1 = ua2; ub0 = ub1; ub1 = ub2;
+  };
+  for (int r = y0 - 1; r <= yend; r += 3) {
+    step(std::integral_constant<int, 0>{}, r);
+    if (r + 1 > yend) break;
+    step(std::integral_constant<int, 1>{}, r + 1);
+    if (r + 2 > yend) break;
+    step(std::integral_constant<int, 2>{}, r + 2);
   }
 }
 
@@ -394,29 +408,37 @@ __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* 
     // u windows hold rows r-1, r, r+1 while row r of (da, ds) is being formed; the rows the NEXT iteration needs
     // (u row r+2, dg row r+1) are requested before this iteration's arithmetic, so with only two waves per SIMD
     // (222 VGPRs) the HBM latency still hides behind ~500 VALU ops
-    Win8 a0, a1 = load_win8<NARROW>(p1, y0 - 2, x0, H, W), a2 = load_win8<NARROW>(p1, y0 - 1, x0, H, W);
-    Win8 b0, b1 = load_win8<NARROW>(p2, y0 - 2, x0, H, W), b2 = load_win8<NARROW>(p2, y0 - 1, x0, H, W);
+    // Three window slots per channel and three gate-row slots whose roles rotate with the row phase; the row loop is
+    // unrolled by three so the slot indices are compile-time constants (the shifts of the rolling windows were 22 %
+    // of the loop's instructions, and the kernel is VALU-issue-bound).  Only the prefetched rows (na, nb, ng: requested
+    // one iteration ahead, before the arithmetic) are copied into their slot.
+    Win8 A[3], Bw[3];
+    GateRow G[3];
+    A[1] = load_win8<NARROW>(p1, y0 - 2, x0, H, W); A[2] = load_win8<NARROW>(p1, y0 - 1, x0, H, W);
+    Bw[1] = load_win8<NARROW>(p2, y0 - 2, x0, H, W); Bw[2] = load_win8<NARROW>(p2, y0 - 1, x0, H, W);
     Win8 na = load_win8<NARROW>(p1, y0, x0, H, W), nb = load_win8<NARROW>(p2, y0, x0, H, W);
     Win6 ng = load_win6<false, NARROW>(gp, y0 - 1, x0, H, W);
-    GateRow gm, gc;                              // rows r-2 and r-1
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { gm.da1[i] = gm.da2[i] = gm.ds1[i] = gm.ds2[i] = 0.f; gc = gm; }
-    for (int r = y0 - 1; r <= yend; ++r) {
-      a0 = a1; a1 = a2; a2 = na;
-      b0 = b1; b1 = b2; b2 = nb;
+    for (int i = 0; i < 6; ++i) { G[1].da1[i] = G[1].da2[i] = G[1].ds1[i] = G[1].ds2[i] = 0.f; }
+    G[2] = G[1];
+    auto step = [&](auto PH, int r) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value;
+      constexpr int s0 = (ph + 1) % 3, s1 = (ph + 2) % 3, s2 = ph;     // rows r-1, r, r+1 of u; rows r-2, r-1, r of (da, ds)
+      A[s2] = na; Bw[s2] = nb;
       const Win6 dgr = ng;                                     // zero outside the image => da = ds = 0 there
       na = load_win8<NARROW>(p1, r + 2, x0, H, W);
       nb = load_win8<NARROW>(p2, r + 2, x0, H, W);
       ng = load_win6<false, NARROW>(gp, r + 1, x0, H, W);
-      const GateRow gn = gate_bwd_row(a0, a1, a2, b0, b1, b2, dgr, wa, wb);
+      G[s2] = gate_bwd_row(A[s0], A[s1], A[s2], Bw[s0], Bw[s1], Bw[s2], dgr, wa, wb);
+      const GateRow &gm = G[s0], &gc = G[s1], &gn = G[s2];
       if (r >= y0 && r < yend) {                               // weight gradients: this lane's own pixels of row r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float d1 = e < dup ? 0.f : gn.da1[e + 1], d2 = e < dup ? 0.f : gn.da2[e + 1];
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
-            acc1[dx] += d1 * a0.v[e + dx + 1]; acc1[3 + dx] += d1 * a1.v[e + dx + 1]; acc1[6 + dx] += d1 * a2.v[e + dx + 1];
-            acc2[dx] += d2 * b0.v[e + dx + 1]; acc2[3 + dx] += d2 * b1.v[e + dx + 1]; acc2[6 + dx] += d2 * b2.v[e + dx + 1];
+            acc1[dx] += d1 * A[s0].v[e + dx + 1]; acc1[3 + dx] += d1 * A[s1].v[e + dx + 1]; acc1[6 + dx] += d1 * A[s2].v[e + dx + 1];
+            acc2[dx] += d2 * Bw[s0].v[e + dx + 1]; acc2[3 + dx] += d2 * Bw[s1].v[e + dx + 1]; acc2[6 + dx] += d2 * Bw[s2].v[e + dx + 1];
           }
         }
       }
@@ -433,7 +455,13 @@ __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* 
         store_px4<NARROW>(o1, q, x0, W, d1);
         store_px4<NARROW>(o2, q, x0, W, d2);
       }
-      gm = gc; gc = gn;
+    };
+    for (int r = y0 - 1; r <= yend; r += 3) {
+      step(std::integral_constant<int, 0>{}, r);
+      if (r + 1 > yend) break;
+      step(std::integral_constant<int, 1>{}, r + 1);
+      if (r + 2 > yend) break;
+      step(std::integral_constant<int, 2>{}, r + 2);
     }
   }
 #pragma unroll

@@ -26,6 +26,8 @@ def cases(B, h, H, W):
     px = B * h * H * W * 4
     return {
         "dw3x3 fwd (2h)": (lambda: ops.dw3x3(pin, w, None, 2 * h, u, B, 2 * h, H, W), 4 * px),
+        "dw+gate fwd": (lambda: lib().call("cidnet_iel_dw_gate_fwd", ops._p(pin), ops._p(w), ops._p(w1), ops._p(w2), ops._p(u), ops._p(gate),
+                                           B, h, H, W, ops._stream()), 5 * px),
         "gate fwd": (lambda: lib().call("cidnet_iel_gate_fwd", ops._p(u), ops._p(w1), ops._p(w2), ops._p(gate), B, h, H, W, ops._stream()), 3 * px),
         "gate+dw bwd": (lambda: lib().call("cidnet_iel_gate_dw_bwd", ops._p(u), ops._p(w1), ops._p(w2), ops._p(dg), ops._p(out), ops._p(g1),
                                            ops._p(g2), ops._p(ws), ws.numel(), B, h, H, W, ops._stream()), 5 * px),
