@@ -284,3 +284,42 @@ def test_cidnet_tnsm_golden(golden, dev):
     with torch.no_grad():
         ye, fe = m(_t(g["model_x"], dev))
     assert fe is None and ye.shape == y.shape
+
+
+@pytest.mark.parametrize("shape,quantised", [((1, 3, 8, 8), False), ((2, 3, 16, 24), True), ((1, 3, 40, 56), False),
+                                             ((3, 3, 24, 104), False), ((1, 3, 104, 40), True), ((1, 3, 8, 200), False)])
+def test_cidnet_shape_sweep_vs_oracle(dev, shape, quantised):
+    """ragged and degenerate sizes against the oracle run live on the host: planes narrower than one 4-pixel lane
+    group at the deeper levels (8x8 input => 4x4, 2x2, 1x1 planes: the per-element loaders, bilinear resampling
+    to and from a single pixel), widths that are not multiples of 4 after downsampling, batch 3, uint8-like inputs
+    with many channel ties.  Forward at the north-star bar (1e-4 abs) against the fp32 oracle; gradients of a smooth
+    objective against the oracle evaluated in fp64 (the fp32 host evaluation is itself up to 1e-2 off on these
+    small planes, tools/diag_shapes.py), bar 5e-4 of each tensor's max + 5e-6 (scalar gradients of tiny magnitude
+    -- PReLU slopes, temperatures -- carry fp32 summation noise of that absolute size)."""
+    import hvi_cidnet_amd as P
+    chans = (12, 12, 24, 48)
+    p = O.make_params(11, channels=chans)
+    m = P.CIDNet(channels=list(chans))
+    load(m, p)
+    m.to(dev)
+    x = O.synthetic_batch(101 + shape[2], shape, quantised=quantised)
+    r = O.synthetic_batch(202 + shape[3], shape) - 0.5
+    y = m(x.to(dev))
+    (y * r.to(dev)).sum().backward()
+    with torch.no_grad():
+        out_ok(y, O.cidnet_forward(p, x).numpy(), 1e-4, f"fwd {shape}")
+    po = O.params_to(p, dtype=torch.float64, requires_grad=True)
+    yo = O.cidnet_forward(po, x.double())
+    (yo * r.double()).sum().backward()
+    out_ok(y, yo.detach().numpy(), 1e-4, f"fwd vs fp64 {shape}")
+    n_checked = 0
+    for n, prm in m.named_parameters():
+        if n.startswith("I_LCA5."):
+            assert prm.grad is None
+            continue
+        g = po[n].grad
+        d = (prm.grad.detach().cpu().double() - g).abs().max().item()
+        tol = 5e-4 * g.abs().max().item() + 5e-6
+        assert d <= tol, f"d{n} {shape}: max diff {d:.3e} > {tol:.3e}"
+        n_checked += 1
+    assert n_checked == 191 - 13
