@@ -135,11 +135,23 @@ def main():
     for _ in range(max(a.warmup, 1)):
         loss = trainer.step(x, gt)
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]   # per-step diagnostics only (stderr)
+    host = []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = trainer.step(x, gt)
+        marks[i + 1].record()
+        host.append(time.perf_counter())
     sync()
     dt = time.perf_counter() - t0
+    if rank == 0:
+        raw_enq = [1e3 * (b - c) for b, c in zip(host, [t0] + host[:-1])]
+        gpu_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+        enq_ms = sorted(raw_enq)
+        print(f"[bench] slowest host enqueue at timed step {raw_enq.index(enq_ms[-1])}", file=sys.stderr)
+        print(f"[bench] per-step ms on the main stream: min {gpu_ms[0]:.2f} median {gpu_ms[len(gpu_ms) // 2]:.2f} max {gpu_ms[-1]:.2f}; "
+              f"host enqueue per step: min {enq_ms[0]:.2f} median {enq_ms[len(enq_ms) // 2]:.2f} max {enq_ms[-1]:.2f}", file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

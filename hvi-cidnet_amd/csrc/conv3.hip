@@ -33,6 +33,7 @@ struct C3Args {
   const float* X; long x_bs;
   const float* Wt; long w_ms, w_ks;   // A[m][k][tap] = Wt[m*w_ms + k*w_ks + tap']
   float* Y; long y_bs;
+  const float* R; long r_bs;          // optional addend of the output's shape (Y = conv + R), or nullptr
   int M, K, H, W;
   int flip;        // tap' = 8 - tap (data gradient)
   int replicate;   // border mode of the input
@@ -111,7 +112,9 @@ constexpr int c3_lda(int mb) { return ((mb + 15) / 32) * 32 + 16; }   // smalles
 
 __device__ __forceinline__ float pick4(f32x4 v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
 
-template <int MT, int LEFT, int LOGX, bool NARROW>
+// ADD: the epilogue adds a.R (a separate instantiation: folded into the plain kernel, the addend loads cost the
+// 48-row variant its second wave per SIMD)
+template <int MT, int LEFT, int LOGX, bool NARROW, bool ADD>
 __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   extern __shared__ float As[];                 // [kKC][9][ldA]
   constexpr int MB = 16 * MT + 4 * LEFT;        // output channels of one block
@@ -345,28 +348,32 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
         for (int reg = 0; reg < 4; ++reg) {
           const int m = m0 + mt * 16 + j * 4 + reg;
           if (m >= a.M) continue;
-          float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
-          const f32x4 v = {acc[r][mt][0][reg], acc[r][mt][1][reg], acc[r][mt][2][reg], acc[r][mt][3][reg]};
+          const long off = (long)m * HW + (long)y * W;
+          float* row = a.Y + (long)b * a.y_bs + off;
+          f32x4 v = {acc[r][mt][0][reg], acc[r][mt][1][reg], acc[r][mt][2][reg], acc[r][mt][3][reg]};
           if (!NARROW) {
+            if (ADD) v += load4u(a.R + (long)b * a.r_bs + off + xq);
             store4u(row + xq, v);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (x0 + e < W) row[x0 + e] = v[e];
+              if (x0 + e < W) row[x0 + e] = v[e] + (ADD ? a.R[(long)b * a.r_bs + off + x0 + e] : 0.f);
           }
         }
 #pragma unroll
       for (int lg = 0; lg < LEFT; ++lg) {          // lane (c, j) stores row 16*MT + 4*lg + j of the 4-row group
         const int m = m0 + MT * 16 + lg * 4 + j;
         if (m >= a.M) continue;
-        float* row = a.Y + (long)b * a.y_bs + (long)m * HW + (long)y * W;
-        const f32x4 v = {pick4(accl[r][lg][0], j), pick4(accl[r][lg][1], j), pick4(accl[r][lg][2], j), pick4(accl[r][lg][3], j)};
+        const long off = (long)m * HW + (long)y * W;
+        float* row = a.Y + (long)b * a.y_bs + off;
+        f32x4 v = {pick4(accl[r][lg][0], j), pick4(accl[r][lg][1], j), pick4(accl[r][lg][2], j), pick4(accl[r][lg][3], j)};
         if (!NARROW) {
+          if (ADD) v += load4u(a.R + (long)b * a.r_bs + off + xq);
           store4u(row + xq, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (x0 + e < W) row[x0 + e] = v[e];
+            if (x0 + e < W) row[x0 + e] = v[e] + (ADD ? a.R[(long)b * a.r_bs + off + x0 + e] : 0.f);
         }
       }
     }
@@ -394,7 +401,10 @@ int launch_c3x(C3Args a, int B, hipStream_t s) {
   }
   a.tpb = (int)tpb;
   dim3 grid((unsigned)xt, (unsigned)((ntiles + tpb - 1) / tpb), (unsigned)(B * a.nmb));
-  hipLaunchKernelGGL((conv3_kernel<MT, LEFT, LOGX, NARROW>), grid, dim3(kThreads), lds, s, a);
+  if (a.R)
+    hipLaunchKernelGGL((conv3_kernel<MT, LEFT, LOGX, NARROW, true>), grid, dim3(kThreads), lds, s, a);
+  else
+    hipLaunchKernelGGL((conv3_kernel<MT, LEFT, LOGX, NARROW, false>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -764,11 +774,13 @@ extern "C" {
 
 void cidnet_debug_c3_flags(int flags) { g_c3_dbg = flags; }
 
-int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, int replicate, float* Y,
-                   long y_bs, int B, int M, int K, int H, int W, void* stream) {
+int cidnet_conv3x3_add(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, int replicate, const float* R,
+                       long r_bs, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(X && Wt && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
+  // the addend lives in the MFMA kernel's epilogue; the streaming kernels of <= 4-channel layers do not take one
+  CIDNET_CHECK_ARG(!R || !(c3_thin_applies(M, K) && !(g_c3_dbg & 8)));
   C3Args a{};
-  a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs;
+  a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs; a.R = R; a.r_bs = r_bs;
   a.M = M; a.K = K; a.H = H; a.W = W; a.flip = flip; a.replicate = replicate; a.dbg = g_c3_dbg;
   if (c3_thin_applies(M, K) && !(g_c3_dbg & 8))
     return c3_thin_conv(X, x_bs, Wt, w_ms, w_ks, flip, replicate, Y, y_bs, B, M, K, H, W, (hipStream_t)stream);
@@ -788,6 +800,11 @@ int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w
     case 9: return launch_c3<2, 1>(a, B, s);
     default: return launch_c3<3, 0>(a, B, s);
   }
+}
+
+int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, int replicate, float* Y,
+                   long y_bs, int B, int M, int K, int H, int W, void* stream) {
+  return cidnet_conv3x3_add(X, x_bs, Wt, w_ms, w_ks, flip, replicate, nullptr, 0, Y, y_bs, B, M, K, H, W, stream);
 }
 
 long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W) {

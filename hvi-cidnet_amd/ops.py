@@ -236,9 +236,14 @@ def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None)
                ws.numel(), B, C, H, W, _stream())
 
 
-def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False):
-    lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
-               H, W, _stream())
+def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None):
+    """y = conv3x3(x) (+ addend, in the kernel's epilogue; only for layers with more than 4 channels on both sides)"""
+    if addend is None:
+        lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
+                   H, W, _stream())
+    else:
+        lib().call("cidnet_conv3x3_add", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(addend), M * H * W,
+                   _p(y), M * H * W, B, M, K, H, W, _stream())
 
 
 def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False):
@@ -504,6 +509,39 @@ class DownFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             conv3x3(dt, w, dx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True)
+        return dx, gw, dslope
+
+
+class DownResFn(torch.autograd.Function):
+    """NormDownsample whose input also feeds a skip connection (net/CIDNet.py:80-81,85-86: `i_jump0 = i_enc0`, ...):
+    returns (down(x), x).  The skip consumer takes the second output, so its gradient arrives HERE and is added in the
+    epilogue of the data-gradient conv instead of by autograd's separate accumulation pass over the tensor (two
+    69M-element passes per step at 400x600, two more at 200x300)."""
+
+    @staticmethod
+    def forward(ctx, x, w, slope):
+        out = DownFn.forward(ctx, x, w, slope)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, go, gres):
+        x, w, slope, pre = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co = w.shape[0]
+        if go is None:
+            return gres, None, None
+        if gres is None or min(Ci, Co) <= 4:
+            dx, gw, dslope = DownFn.backward(ctx, go)
+            if gres is not None and dx is not None:
+                dx = dx + gres
+            return dx, gw, dslope
+        dpre, dslope = prelu_bwd(_c(go), pre, slope)
+        dt = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
+        bilinear_bwd(dpre, dt, B, Co, H, W, H // 2, W // 2)
+        gw = grad_like(w)
+        _offload_wgrad((dt, x, gw), lambda: conv3x3_wgrad(dt, x, gw, B, Co, Ci, H, W))
+        dx = torch.empty_like(x)
+        conv3x3(dt, w, dx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True, addend=_c(gres))
         return dx, gw, dslope
 
 

@@ -139,6 +139,13 @@ int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, con
 void cidnet_debug_c3_flags(int flags);
 int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
                    int replicate, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
+/* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
+ * NormDownsample when its input also feeds a skip connection (net/CIDNet.py:80-81,85-86): the skip's gradient is
+ * added in the epilogue instead of by a separate pass over the tensor.  Layers with <= 4 channels on a side
+ * (streaming kernels) do not take an addend: CIDNET_ERR_ARG. */
+int cidnet_conv3x3_add(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
+                       int replicate, const float* R, long r_bs, float* Y, long y_bs, int B, int M, int K,
+                       int H, int W, void* stream);
 long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W);
 int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int replicate,
                          float* dW, float* ws, long ws_floats, int B, int M, int N, int H, int W,

@@ -131,6 +131,32 @@ def test_conv3x3(dev, B, Ci, Co, H, W, rep):
         close(gw, wr.grad, what="wgrad")
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 36, 36, 16, 24), (1, 72, 36, 10, 15), (1, 12, 24, 9, 70), (1, 24, 12, 4, 4), (1, 144, 72, 25, 37)])
+def test_conv3x3_addend_and_down_skip(dev, B, Ci, Co, H, W):
+    """cidnet_conv3x3_add == conv + addend bitwise (same kernel body, one more load in the epilogue), and the
+    NormDownsample-with-skip function gives the gradients of the plain block plus the skip's gradient"""
+    from hvi_cidnet_amd import ops
+    x, w, r = rnd(31, (B, Ci, H, W)).to(dev), rnd(32, (Co, Ci, 3, 3), 0.3).to(dev), rnd(33, (B, Co, H, W)).to(dev)
+    y0, y1 = torch.empty_like(r), torch.empty_like(r)
+    ops.conv3x3(x, w, y0, B, Co, Ci, H, W, 9 * Ci, 9)
+    ops.conv3x3(x, w, y1, B, Co, Ci, H, W, 9 * Ci, 9, addend=r)
+    assert torch.equal(y1, y0 + r)
+    if H % 2 or W % 2:
+        return
+    slope = torch.tensor([0.2], device=dev)
+    go, gs = rnd(34, (B, Co, H // 2, W // 2)).to(dev), rnd(35, (B, Ci, H, W)).to(dev)
+    xa, wa, sa = (t.clone().requires_grad_(True) for t in (x, w, slope))
+    ya = ops.DownFn.apply(xa, wa, sa)
+    ya.backward(go)
+    xb, wb, sb = (t.clone().requires_grad_(True) for t in (x, w, slope))
+    yb, xs = ops.DownResFn.apply(xb, wb, sb)
+    assert xs.data_ptr() == xb.data_ptr()
+    torch.autograd.backward([yb, xs], [go, gs])
+    assert torch.equal(ya, yb)
+    close(xb.grad, xa.grad + gs, what="dgrad + skip")
+    assert torch.equal(wb.grad, wa.grad) and torch.equal(sb.grad, sa.grad)
+
+
 @pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 5, 16, 24, 8, 12), (1, 3, 17, 23, 8, 11), (2, 4, 8, 12, 16, 24), (1, 2, 50, 75, 100, 150)])
 def test_bilinear_bwd_and_down(dev, B, C, Hi, Wi, Ho, Wo):
     from hvi_cidnet_amd import ops
