@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const float* __re
     Bw[s2] = load_win8<NARROW>(p2, r + 1, x0, H, W);
     UA[s2] = u_row(A[s0], A[s1], A[s2], wpa, r);
     UB[s2] = u_row(Bw[s0], Bw[s1], Bw[s2], wpb, r);
-    if (r >= y0 && r < yend) {
+    if (u != nullptr && r >= y0 && r < yend) {     // u == nullptr: inference, nothing reads u back
       store_px4<NARROW>(u1, r, x0, W, f32x4{UA[s2].v[1], UA[s2].v[2], UA[s2].v[3], UA[s2].v[4]});
       store_px4<NARROW>(u2, r, x0, W, f32x4{UB[s2].v[1], UB[s2].v[2], UB[s2].v[3], UB[s2].v[4]});
     }
@@ -558,7 +558,7 @@ int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float*
 
 int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g, int B, int h,
                            int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(pin && wdw && w1 && w2 && u && g && B > 0 && h > 0 && H > 0 && W > 0);
+  CIDNET_CHECK_ARG(pin && wdw && w1 && w2 && g && B > 0 && h > 0 && H > 0 && W > 0);   // u may be NULL (not stored)
   const Tiling tl = dw_gate_tiling((long)B * h, H, W);
   const long items = n_items((long)B * h, tl);
   CIDNET_LAUNCH_NW(W, (iel_dw_gate_kernel<true>), (iel_dw_gate_kernel<false>), dim3((unsigned)((items + kThreads - 1) / kThreads)),

@@ -434,12 +434,15 @@ class IELFn(torch.autograd.Function):
         dev = xn.device
         pin = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32)
         pw_conv(xn, 0, C * HW, w_in, 0, 0, C, 1, pin, 0, 2 * h * HW, B, 2 * h, C, HW)
-        u = torch.empty_like(pin)
+        train = any(ctx.needs_input_grad)               # inference: u (read only by the backward) is not stored
+        u = torch.empty_like(pin) if train else None
         gate = torch.empty((B, h, H, W), device=dev, dtype=torch.float32)
-        lib().call("cidnet_iel_dw_gate_fwd", _p(pin), _p(w_dw), _p(w_dw1), _p(w_dw2), _p(u), _p(gate), B, h, H, W, _stream())
+        lib().call("cidnet_iel_dw_gate_fwd", _p(pin), _p(w_dw), _p(w_dw1), _p(w_dw2), _p(u) if train else None, _p(gate), B, h, H, W,
+                   _stream())
         out = torch.empty_like(xn)
         pw_conv(gate, 0, h * HW, w_out, 0, 0, h, 1, out, 0, C * HW, B, C, h, HW, res=res, r_bs=C * HW)
-        ctx.save_for_backward(xn, pin, u, gate, w_in, w_dw, w_dw1, w_dw2, w_out)
+        if train:
+            ctx.save_for_backward(xn, pin, u, gate, w_in, w_dw, w_dw1, w_dw2, w_out)
         ctx.has_res = res is not None
         return out
 
@@ -488,10 +491,12 @@ class DownFn(torch.autograd.Function):
         Co = w.shape[0]
         t = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
         conv3x3(x, w, t, B, Co, Ci, H, W, 9 * Ci, 9)
-        pre = torch.empty((B, Co, H // 2, W // 2), device=x.device, dtype=torch.float32)
-        out = torch.empty_like(pre)
+        train = any(ctx.needs_input_grad)               # inference: the pre-activation (read by the backward) is not stored
+        out = torch.empty((B, Co, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        pre = torch.empty_like(out) if train else None
         lib().call("cidnet_down_prelu_fwd", _p(t), _p(slope), _p(pre), _p(out), B, Co, H, W, _stream())
-        ctx.save_for_backward(x, w, slope, pre)
+        if train:
+            ctx.save_for_backward(x, w, slope, pre)
         return out
 
     @staticmethod
@@ -563,11 +568,13 @@ class UpFn(torch.autograd.Function):
         conv3x3(x, w, t, B, Co, Ci, h, wd, 9 * Ci, 9)
         z = torch.empty_like(t)
         pw_conv(t, 0, Co * h * wd, w_up, 0, 0, 2 * Co, 1, z, 0, Co * h * wd, B, Co, Co, h * wd)
+        train = any(ctx.needs_input_grad)
         out = torch.empty_like(skip)
-        pre = torch.empty_like(skip)
+        pre = torch.empty_like(skip) if train else None
         lib().call("cidnet_pw_conv_up_prelu", _p(skip), Co * 4 * h * wd, _po(w_up, Co), 2 * Co, 1, _p(z), _p(slope), _p(out),
                    _p(pre), B, Co, Co, h, wd, _stream())
-        ctx.save_for_backward(x, skip, w, w_up, slope, t, pre)
+        if train:
+            ctx.save_for_backward(x, skip, w, w_up, slope, t, pre)
         return out
 
     @staticmethod

@@ -89,7 +89,7 @@ int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w
                    float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
                    void* stream);
 /* NormUpsample tail (net/transformer_utils.py:64-66): pre = Wt*X + bilinear_x2(Z), Y = PReLU(pre).
- * Z: (B,M,zh,zw) low-resolution, X: skip tensor (B,K,2zh,2zw), Y/Ypre: (B,M,2zh,2zw). */
+ * Z: (B,M,zh,zw) low-resolution, X: skip tensor (B,K,2zh,2zw), Y/Ypre: (B,M,2zh,2zw); Ypre may be NULL (inference). */
 int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks,
                             const float* Z, const float* slope, float* Y, float* Ypre, int B, int M,
                             int K, int zh, int zw, void* stream);
@@ -115,7 +115,8 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
                      const float* addend, float* gin, float* gw1, float* gw2, float* ws,
                      long ws_floats, int B, int C, int H, int W, void* stream);
 /* g = (tanh(dw1(u1)) + u1) * (tanh(dw2(u2)) + u2);  u: (B,2h,H,W) = [u1;u2], g: (B,h,H,W). */
-/* u = dw3x3(pin, wdw) (2h channels) and g = gate(u) in one pass (net/LCA.py:61-65): u is written once and never re-read */
+/* u = dw3x3(pin, wdw) (2h channels) and g = gate(u) in one pass (net/LCA.py:61-65): u is written once and never re-read.
+ * u may be NULL: inference, where only the backward would read u -- the kernel then stores g alone. */
 int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g,
                            int B, int h, int H, int W, void* stream);
 int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h,
@@ -156,6 +157,7 @@ int cidnet_conv3x3_replicate_dgrad_fix(const float* gY, const float* Wt, float* 
 
 /* ---- resampling / PReLU pieces of NormDownsample, NormUpsample ---------------------------------
  * (nn.UpsamplingBilinear2d == bilinear, align_corners=True; nn.PReLU with one slope) */
+/* pre (the pre-activation, read only by cidnet_prelu_bwd) may be NULL: inference. */
 int cidnet_down_prelu_fwd(const float* t, const float* slope, float* pre, float* out, int B, int C,
                           int H, int W, void* stream);
 long cidnet_prelu_bwd_ws_floats(void);
