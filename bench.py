@@ -149,7 +149,8 @@ def main():
         raw_enq = [1e3 * (b - c) for b, c in zip(host, [t0] + host[:-1])]
         gpu_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
         enq_ms = sorted(raw_enq)
-        print(f"[bench] slowest host enqueue at timed step {raw_enq.index(enq_ms[-1])}", file=sys.stderr)
+        slow = [(i, round(v, 1)) for i, v in enumerate(raw_enq) if v > 5 * enq_ms[len(enq_ms) // 2]]
+        print(f"[bench] slowest host enqueue at timed step {raw_enq.index(enq_ms[-1])}; steps slower than 5x the median: {slow}", file=sys.stderr)
         print(f"[bench] per-step ms on the main stream: min {gpu_ms[0]:.2f} median {gpu_ms[len(gpu_ms) // 2]:.2f} max {gpu_ms[-1]:.2f}; "
               f"host enqueue per step: min {enq_ms[0]:.2f} median {enq_ms[len(enq_ms) // 2]:.2f} max {enq_ms[-1]:.2f}", file=sys.stderr, flush=True)
     if world > 1:

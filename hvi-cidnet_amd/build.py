@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libcidnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC]
+          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC, *os.environ.get("CIDNET_EXTRA_FLAGS", "").split()]
 # hvi.hip mirrors the reference's fp32 operation order (bit-exact masks/sextants): no implicit FMA
 # dw.hip: the SLP vectoriser packs the stencil FMAs into v_pk_fma_f32 and pays for it with register-pair shuffles
 # (more instructions in total, and past 256 VGPRs in the gate backward): the kernels there are VALU-issue-bound

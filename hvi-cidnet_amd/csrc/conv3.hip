@@ -18,6 +18,7 @@
 //   the four j-shares are added across lanes (xor 16, 32) once per tile, and lane j stores row 32 + j.
 //   Weights (A operand) are staged per 16-channel chunk in LDS as [ci][tap][co] with a leading
 //   dimension == 16 (mod 32): conflict-free ds_read_b32.
+#include <type_traits>
 #include "common.h"
 #include "conv3_thin.h"
 
@@ -27,6 +28,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kR = 2;      // output rows per wave
 constexpr int kKC = 36;    // input channels staged per chunk (9 k-groups)
+constexpr int kStageBatch = 6;   // 16-byte weight loads a thread keeps in flight while staging the panel
 int g_c3_dbg = 0;
 
 struct C3Args {
@@ -108,17 +110,37 @@ __device__ __forceinline__ Win6 finish_win(const RawWin6& w, int yy, int xq, int
 
 // LOGX: log2 of the lanes (x 4 pixels) a 16-lane group spends on x; the other 16>>LOGX lanes take
 // further rows, so narrow images (W = 75, 150) do not waste most of a 64-pixel-wide tile.
-constexpr int c3_lda(int mb) { return ((mb + 15) / 32) * 32 + 16; }   // smallest >= mb that is 16 (mod 32)
+// The weight panel sits in LDS in the ORDER OF ITS SOURCE ROWS, so staging is a straight 16-byte copy (a scatter into a
+// [k][tap][m] image cost 48 kcycles per block: every lane of a store hit the same bank).  Element (m, k, tap) is at
+// m*sm + k*sk + tap with
+//   forward layout  Wt[m][k][tap] (w_ks == 9): one LDS row per output channel, sm = c3_ldm(k-extent*9), sk = 9;
+//   data-gradient   Wt[k][m][tap] (w_ms == 9): one LDS row per input channel,  sm = 9, sk = c3_ldk(MB*9).
+// The row strides make the A-operand reads (16 lanes over m, 4 lane groups over k) conflict-free: banks 2c + 9j with
+// the stride 2 (mod 32), banks 9c + 16j with the stride 16 (mod 32), distinct inside each 32-lane half.
+constexpr int c3_ldm(int rowlen) { return ((rowlen + 29) / 32) * 32 + 2; }    // smallest >= rowlen that is 2 (mod 32)
+constexpr int c3_ldk(int rowlen) { return ((rowlen + 15) / 32) * 32 + 16; }   // smallest >= rowlen that is 16 (mod 32)
+constexpr int c3_lds_floats(int mb, int kq) {
+  const int f = mb * c3_ldm(kq * 9), d = kq * c3_ldk(mb * 9);
+  return f > d ? f : d;
+}
 
 __device__ __forceinline__ float pick4(f32x4 v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+
+// Phase timing study (build with -DC3_TIMING, tools/c3_phases.py): wave 0 of every block adds up the shader-clock
+// cycles it spends staging weights, in the k loops and in the epilogues.  Not compiled into the product library.
+#ifdef C3_TIMING
+__device__ unsigned long long g_c3_phase[4 * 8192];
+#define C3_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define C3_T(var)
+#endif
 
 // ADD: the epilogue adds a.R (a separate instantiation: folded into the plain kernel, the addend loads cost the
 // 48-row variant its second wave per SIMD)
 template <int MT, int LEFT, int LOGX, bool NARROW, bool ADD>
 __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
-  extern __shared__ float As[];                 // [kKC][9][ldA]
+  extern __shared__ float As[];                 // weight panel of one k chunk, source-row order (see c3_ldm)
   constexpr int MB = 16 * MT + 4 * LEFT;        // output channels of one block
-  constexpr int ldA = c3_lda(MB);
   constexpr int LG = LEFT > 0 ? LEFT : 1;       // array extent (LEFT = 0: unused)
   constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
   constexpr int TROWS = 4 * NY * kR;            // output rows of one block tile
@@ -138,79 +160,82 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
   // layout, (m,tap) for the data-gradient layout) with 16 B loads: a thread takes 4 consecutive elements of a row,
   // decodes them with constant divisors and scatters them to [k][tap][m].  (One 4 B load + two run-time integer
   // divisions per element made this staging cost half a tile's MFMA time.)
+  const bool fwd_layout = a.w_ks == 9 || a.w_ms != 9;      // generic strides are staged element-wise into the forward image
+  const int kq_max = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
+  const int sm = fwd_layout ? c3_ldm(kq_max * 9) : 9;
+  const int sk = fwd_layout ? 9 : c3_ldk(MB * 9);
   auto stage = [&](int kc0, int kcn, int ng) {
     const int kq = ng * 4;
-    if (a.w_ks == 9) {
-      const int rowlen = kq * 9, nv = (rowlen + 3) >> 2, valid = kcn * 9;      // per output channel: (k,tap) run
-      for (int i = tid; i < MB * nv; i += kThreads) {
-        const int mm = i / nv, v = i - mm * nv;
-        const int e0 = 4 * v;
-        float x[4] = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + mm < a.M) {
-          const float* src = a.Wt + (long)(m0 + mm) * a.w_ms + (long)kc0 * 9 + e0;
-          if (e0 + 3 < valid) {
-            const f32x4 q = load4u(src);
-            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (e0 + q < valid) x[q] = src[q];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = e0 + q;
-          if (e < rowlen) {
-            const int kk = e / 9, t = e - kk * 9;
-            As[(kk * 9 + (a.flip ? 8 - t : t)) * ldA + mm] = x[q];
-          }
-        }
+    if (a.w_ks != 9 && a.w_ms != 9) {             // generic strides: element-wise
+      for (int i = tid; i < kq * MB * 9; i += kThreads) {
+        const int kk = i / (MB * 9), rem = i - kk * (MB * 9);
+        const int mm = rem / 9, t = rem - mm * 9;
+        float v = 0.f;
+        if (kk < kcn && m0 + mm < a.M) v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + t];
+        As[mm * sm + kk * sk + t] = v;
       }
-    } else {
-      // data-gradient layout: Wt[(m0+mm)*9 + (kc0+kk)*w_ks + tap] (w_ms == 9): for one kk the run over (mm,tap) is contiguous
-      const int rowlen = MB * 9, nv = (rowlen + 3) >> 2;
-      const int valid = (a.M - m0 < MB ? a.M - m0 : MB) * 9;
-      if (a.w_ms != 9) {                          // generic strides: element-wise
-        for (int i = tid; i < kq * MB * 9; i += kThreads) {
-          const int kk = i / (MB * 9), rem = i - kk * (MB * 9);
-          const int mm = rem / 9, t = rem - mm * 9;
-          float v = 0.f;
-          if (kk < kcn && m0 + mm < a.M)
-            v = a.Wt[(long)(m0 + mm) * a.w_ms + (long)(kc0 + kk) * a.w_ks + (a.flip ? 8 - t : t)];
-          As[(kk * 9 + t) * ldA + mm] = v;
-        }
-        return;
-      }
-      for (int i = tid; i < kq * nv; i += kThreads) {
-        const int kk = i / nv, v = i - kk * nv;
-        const int e0 = 4 * v;
-        float x[4] = {0.f, 0.f, 0.f, 0.f};
-        if (kk < kcn) {
-          const float* src = a.Wt + (long)m0 * 9 + (long)(kc0 + kk) * a.w_ks + e0;
-          if (e0 + 3 < valid) {
-            const f32x4 q = load4u(src);
-            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
-          } else {
+      return;
+    }
+    // nrows rows of rowlen floats: a valid prefix copied from global, the rest (and whole invalid rows) zero
+    const int nrows = fwd_layout ? MB : kq;
+    const int rowlen = fwd_layout ? kq * 9 : MB * 9;
+    const int valid = fwd_layout ? kcn * 9 : (a.M - m0 < MB ? a.M - m0 : MB) * 9;
+    const int rows_ok = fwd_layout ? (a.M - m0 < MB ? a.M - m0 : MB) : kcn;
+    const long gs = fwd_layout ? a.w_ms : a.w_ks;
+    const int ls = fwd_layout ? sm : sk;
+    const float* base = fwd_layout ? a.Wt + (long)m0 * a.w_ms + (long)kc0 * 9 : a.Wt + (long)m0 * 9 + (long)kc0 * a.w_ks;
+    // 256 threads = 8 rows x 32 float4 lanes per pass (no run-time division anywhere: the two per element of a flat
+    // index were most of what was left of the staging time); kStageBatch row groups are loaded before the first LDS
+    // write, so a pass over the panel pays the L2 round trip once
+    // Every resident block wants the same panel at the same moment: read in the same order, all CUs queue on one L2
+    // channel at a time (13-27 kcycles for 51 KB).  Each block therefore starts at its own row.
+    const int nv = (rowlen + 3) >> 2;
+    const int rsub = tid >> 5, vl = tid & 31;
+    const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u + blockIdx.z * 7u) % (unsigned)nrows);
+    for (int v = vl; v < nv; v += 32) {
+      const int e0 = 4 * v;
+      for (int r0 = rsub; r0 < nrows; r0 += 8 * kStageBatch) {
+        f32x4 q[kStageBatch];
+        int rows[kStageBatch];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (e0 + q < valid) x[q] = src[q];
+        for (int u = 0; u < kStageBatch; ++u) {
+          int row = r0 + 8 * u + rot;
+          if (row >= nrows) row -= nrows;
+          if (r0 + 8 * u >= nrows) row = nrows;   // past the panel: neither loaded nor stored
+          rows[u] = row;
+          q[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (row < rows_ok) {
+            const float* src = base + (long)row * gs + e0;
+            if (e0 + 3 < valid) {
+              q[u] = load4u(src);
+            } else {
+#pragma unroll
+              for (int z = 0; z < 4; ++z)
+                if (e0 + z < valid) q[u][z] = src[z];
+            }
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = e0 + q;
-          if (e < rowlen) {
-            const int mm = e / 9, t = e - mm * 9;
-            As[(kk * 9 + (a.flip ? 8 - t : t)) * ldA + mm] = x[q];
+        for (int u = 0; u < kStageBatch; ++u) {
+          const int row = rows[u];
+          if (row < nrows) {
+            float* dst = As + row * ls + e0;      // 8-byte aligned (both strides are even); rows are padded past rowlen
+            *reinterpret_cast<float2*>(dst) = float2{q[u][0], q[u][1]};
+            *reinterpret_cast<float2*>(dst + 2) = float2{q[u][2], q[u][3]};
           }
         }
       }
     }
   };
+  C3_T(ts0);
   if (single) {
     stage(0, a.K, (a.K + 3) >> 2);
     __syncthreads();
   }
+  C3_T(ts1);
+#ifdef C3_TIMING
+  unsigned long long t_k = 0, t_e = 0;
+#endif
 
   const int ntiles = (H + TROWS - 1) / TROWS;
   const int tile_end = min((int)(blockIdx.y + 1) * a.tpb, ntiles);
@@ -219,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
     const int yw = ywave + (c >> LOGX) * kR;    // first output row of this lane
     const bool wave_live = ywave < H;
 
+    C3_T(tt0);
     f32x4 acc[kR][MT][4];
     f32x4 accl[kR][LG][4];
 #pragma unroll
@@ -266,17 +292,27 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
           }
         }
         float av[9][MT];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[t][mt] = As[(((a.dbg & 4) ? 0 : g * 4 + j) * 9 + t) * ldA + mt * 16 + c];
         float al[9][LG];
-        if (LEFT > 0) {
+        {
+          const float* Ak = As + ((a.dbg & 4) ? 0 : g * 4 + j) * sk;
+          auto fetch = [&](auto FLIP) __attribute__((always_inline)) {
+            constexpr bool flip = decltype(FLIP)::value;
 #pragma unroll
-          for (int t = 0; t < 9; ++t)
+            for (int mt = 0; mt < MT; ++mt) {
+              const float* pa = Ak + (mt * 16 + c) * sm;
 #pragma unroll
-            for (int lg = 0; lg < LEFT; ++lg)
-              al[t][lg] = As[(((a.dbg & 4) ? 0 : g * 4 + j) * 9 + t) * ldA + MT * 16 + lg * 4 + (lane & 3)];
+              for (int t = 0; t < 9; ++t) av[t][mt] = pa[flip ? 8 - t : t];
+            }
+            if (LEFT > 0) {
+#pragma unroll
+              for (int lg = 0; lg < LEFT; ++lg) {
+                const float* pl = Ak + (MT * 16 + lg * 4 + (lane & 3)) * sm;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) al[t][lg] = pl[flip ? 8 - t : t];
+              }
+            }
+          };
+          if (a.flip) fetch(std::true_type{}); else fetch(std::false_type{});
         }
         if (!NARROW) __builtin_amdgcn_sched_barrier(0);     // keep the next group's loads ahead of this group's MFMA burst
 #pragma unroll
@@ -307,6 +343,14 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
       }
     }
 
+#ifdef C3_TIMING
+    const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
+    t_k += tt1 - tt0;
+    struct C3TileEnd {                            // runs on every way out of the tile body (continue included)
+      unsigned long long t1; unsigned long long& acc;
+      __device__ ~C3TileEnd() { acc += __builtin_amdgcn_s_memtime() - t1; }
+    } c3_tile_end{tt1, t_e};
+#endif
     if (LEFT > 0 && wave_live) {                  // add the four k-slot shares of the 4-row groups (all lanes take part)
 #pragma unroll
       for (int r = 0; r < kR; ++r)
@@ -378,27 +422,28 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(C3Args a) {
       }
     }
   }
+#ifdef C3_TIMING
+  if (tid == 0) {
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (blk < 8192) {
+      g_c3_phase[4 * blk + 0] = ts1 - ts0; g_c3_phase[4 * blk + 1] = t_k; g_c3_phase[4 * blk + 2] = t_e; g_c3_phase[4 * blk + 3] = te - ts0;
+    }
+  }
+#endif
 }
 
 template <int MT, int LEFT, int LOGX, bool NARROW>
 int launch_c3x(C3Args a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT + 4 * LEFT;
-  constexpr int ldA = c3_lda(MB);
   constexpr int XL = 1 << LOGX, NY = 16 >> LOGX;
   const int kc = ((a.K < kKC ? a.K : kKC) + 3) & ~3;
-  const size_t lds = (size_t)kc * 9 * ldA * sizeof(float);
+  const size_t lds = (size_t)c3_lds_floats(MB, kc) * sizeof(float);
   const int xt = (a.W + XL * 4 - 1) / (XL * 4);
   const int ntiles = (a.H + 4 * NY * kR - 1) / (4 * NY * kR);
-  long tpb = 1;
-  if (a.K <= kKC) {                              // weights stay resident: walk several row tiles per block
-    // staging the (<= 46 KB) weight panel costs a good part of a tile's MFMA time: amortise it over several tiles, but
-    // only while >= two rounds of resident blocks remain (tools/micro_c3.py, 36->36: 4000 tiles 494/457/456 us at
-    // 1/2/4 tiles per block; 1000 tiles 166/169/238 us); timing study: bits 8..15 of the debug flags force tpb
-    const long tiles = (long)xt * ntiles * B * a.nmb;
-    tpb = tiles / 1024;
-    tpb = tpb < 1 ? 1 : (tpb > 4 ? 4 : tpb);
-    if ((g_c3_dbg >> 8) & 0xFF) tpb = (g_c3_dbg >> 8) & 0xFF;
-  }
+  long tpb = a.tpb > 0 ? a.tpb : 1;             // chosen together with LOGX by launch_c3's cost model
+  if (a.K > kKC) tpb = 1;                        // the panel is re-staged per tile anyway
+  if (((g_c3_dbg >> 8) & 0xFF) && a.K <= kKC) tpb = (g_c3_dbg >> 8) & 0xFF;     // timing study: forced tiles per block
   a.tpb = (int)tpb;
   dim3 grid((unsigned)xt, (unsigned)((ntiles + tpb - 1) / tpb), (unsigned)(B * a.nmb));
   if (a.R)
@@ -410,15 +455,31 @@ int launch_c3x(C3Args a, int B, hipStream_t s) {
 }
 
 template <int MT, int LEFT>
-int launch_c3(const C3Args& a, int B, hipStream_t s) {
-  // pick the x extent of a lane group (64 / 32 / 16 pixels) that wastes the fewest columns
-  int best = 4;
-  long best_cols = 1L << 60;
+int launch_c3(const C3Args& a0, int B, hipStream_t s) {
+  // Tile shape (64 / 32 / 16 pixels wide; every tile is 512 pixels) and row tiles per block, by a cost model in units of
+  // one tile's time.  The blocks of a launch run in lockstep rounds of the 512 resident blocks (2 per CU), so
+  //   cost = rounds * (stage + tiles per block),  rounds = ceil(blocks / 512),  stage ~ 0.15 (tools/c3_phases.py);
+  // a grid of 1064 blocks (36->36 at 200x300 with 16-pixel-wide tiles) pays three rounds for two rounds of work.
+  // Ties go to the shape with less padded work, then to fewer tiles per block.
+  C3Args a = a0;
+  int best = 4, best_tpb = 1;
+  double best_cost = 1e30;
+  long best_work = 1L << 60;
   for (int lx = 4; lx >= 2; --lx) {
-    const int tw = 4 << lx;
-    const long cols = (long)((a.W + tw - 1) / tw) * tw;
-    if (cols < best_cols) { best_cols = cols; best = lx; }
+    const int xl4 = 4 << lx, trows = 4 * (16 >> lx) * kR;
+    const long xt = (a.W + xl4 - 1) / xl4, nt = (a.H + trows - 1) / trows;
+    for (int tpb = 1; tpb <= (a.K <= kKC ? 4 : 1); ++tpb) {
+      const long blocks = xt * ((nt + tpb - 1) / tpb) * B * a.nmb;
+      const long rounds = (blocks + 511) / 512;
+      const double stage = a.K <= kKC ? 0.15 : 0.0;          // deeper layers stage inside every tile: same for all shapes
+      const double cost = (double)rounds * (stage + tpb);
+      const long work = xt * nt;
+      if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && work < best_work)) {
+        best_cost = cost; best_work = work; best = lx; best_tpb = tpb;
+      }
+    }
   }
+  a.tpb = best_tpb;
   if (a.W < 8) return launch_c3x<MT, LEFT, 2, true>(a, B, s);
   if (best == 4) return launch_c3x<MT, LEFT, 4, false>(a, B, s);
   if (best == 3) return launch_c3x<MT, LEFT, 3, false>(a, B, s);
@@ -773,6 +834,18 @@ using namespace cidnet;
 extern "C" {
 
 void cidnet_debug_c3_flags(int flags) { g_c3_dbg = flags; }
+
+#ifdef C3_TIMING
+// copies the per-block phase cycles [stage, k loops, epilogues, total] of the last conv3_kernel launch to the host
+int cidnet_debug_c3_phases(unsigned long long* host, int nblocks) {
+  (void)hipDeviceSynchronize();
+  const size_t n = sizeof(unsigned long long) * 4 * (nblocks < 8192 ? nblocks : 8192);
+  const int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c3_phase), n);
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_c3_phase)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 4 * 8192);
+  return rc;
+}
+#endif
 
 int cidnet_conv3x3_add(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, int replicate, const float* R,
                        long r_bs, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream) {
