@@ -139,8 +139,15 @@ def main():
     host = []
     t0 = time.perf_counter()
     marks[0].record()
+    watchdog = bool(os.environ.get("CIDNET_BENCH_WATCHDOG"))   # diagnostics: dump all Python stacks if one step's enqueue takes > 1 s
+    if watchdog:
+        import faulthandler
     for i in range(a.steps):
+        if watchdog:
+            faulthandler.dump_traceback_later(1.0, file=sys.stderr)
         loss = trainer.step(x, gt)
+        if watchdog:
+            faulthandler.cancel_dump_traceback_later()
         marks[i + 1].record()
         host.append(time.perf_counter())
     sync()

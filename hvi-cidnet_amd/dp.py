@@ -70,8 +70,16 @@ class FlatAdam:
 class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, n_buckets: int = 4, loss_fn: Optional[Callable] = None,
-                 process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = True, use_graph: bool = False):
+                 process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = True, use_graph: bool = False,
+                 max_steps_in_flight: int = 2):
         self.model = model
+        # The host enqueues a step in ~13 ms and the GPU runs it in ~31 ms: left alone, the host is thousands of
+        # launches ahead after ten steps, and the HIP runtime then blocks one launch for 0.5-2.5 s with the GPU idle
+        # (seen in 5 of 8 bench runs, always around the 10th step; a watchdog stack dump showed the autograd thread
+        # inside a kernel launch).  The trainer therefore waits for the step before the previous one before it
+        # enqueues a new one: the queue never holds more than `max_steps_in_flight` steps, the GPU never starves.
+        self.max_steps_in_flight = max(1, int(max_steps_in_flight))
+        self._step_events = []
         self.loss_fn = loss_fn or _default_loss
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -269,14 +277,23 @@ class DataParallelTrainer:
         """forward, loss, backward (+ overlapped bucket all-reduce), fused Adam.  Returns the loss."""
         if not self._ready:
             self._setup(x, gt)
+        if x.is_cuda:
+            while len(self._step_events) >= self.max_steps_in_flight:
+                self._step_events.pop(0).synchronize()
         if self.use_graph and x.is_cuda:
-            return self._graph_step(x, gt)
-        loss = self._fwd_bwd(x, gt)
-        for h in self._handles:
-            h.wait()
-        self._join_wgrad_stream()
-        self.opt.step(self.flat_g, self.n_live, grad_scale=1.0 / self.world)
-        return loss.detach()
+            loss = self._graph_step(x, gt)
+        else:
+            loss = self._fwd_bwd(x, gt)
+            for h in self._handles:
+                h.wait()
+            self._join_wgrad_stream()
+            self.opt.step(self.flat_g, self.n_live, grad_scale=1.0 / self.world)
+            loss = loss.detach()
+        if x.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_events.append(ev)
+        return loss
 
     def forward_backward(self, x, gt):
         """forward + loss + backward only (gradients left in the flat arena); for timing splits."""
