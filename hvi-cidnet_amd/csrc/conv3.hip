@@ -594,6 +594,10 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
   const int ya = rchunk * a.rr, yb = min(ya + a.rr, H);
   const bool rep = a.replicate != 0;
 
+  C3_T(tw0);
+#ifdef C3_TIMING
+  unsigned long long t_wait = 0;
+#endif
   f32x4 acc[9][MT];
   f32x4 accl[9][LG];
 #pragma unroll
@@ -629,6 +633,11 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
     issue_dy(ya);
     for (int y = ya; y < yb; ++y) {
       // consume what was requested one iteration (one MFMA burst) ago ...
+#ifdef C3_TIMING
+      const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // how long do the prefetched rows still take to arrive?
+      t_wait += __builtin_amdgcn_s_memtime() - tq0;
+#endif
       const Win10 w2 = finish_win10(w2raw, y + 1, xq, H, W, rep);
       float av[MT + LG][8];
 #pragma unroll
@@ -669,6 +678,21 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
     }
   }
 
+  C3_T(tw1);
+#ifdef C3_TIMING
+  struct C3WgEnd {                               // [wait for prefetched rows, main loop, epilogue, total] of wave 0
+    unsigned long long t0, t1; unsigned long long& wait;
+    __device__ ~C3WgEnd() {
+      if (threadIdx.x == 0) {
+        const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (blk < 8192) {
+          const unsigned long long te = __builtin_amdgcn_s_memtime();
+          g_c3_phase[4 * blk + 0] = wait; g_c3_phase[4 * blk + 1] = t1 - t0; g_c3_phase[4 * blk + 2] = te - t1; g_c3_phase[4 * blk + 3] = te - t0;
+        }
+      }
+    }
+  } c3_wg_end{tw0, tw1, t_wait};
+#endif
   // sum the four waves' tiles (and, for 4x4x1 results, the four k-slot shares) through LDS, one tap per round
   float* slab = a.slabs + (((long)b * a.nchunk + chunk) * (long)a.M) * a.N * 9;
   constexpr int TILE = (MT + LEFT) * 4;
@@ -765,7 +789,7 @@ inline WgSplit wg_split(int M, int N) {
   if (w.MT == 0 || w.MT + w.LEFT > 3 || (g_c3_dbg & 16)) { w.MT = (rows + 15) / 16; w.LEFT = 0; }
   w.nmb = (M + 16 * w.MT + 4 * w.LEFT - 1) / (16 * w.MT + 4 * w.LEFT);
   w.nfull = N / 16; w.ngrp = ((N % 16) + 3) / 4;
-  if (w.nfull == 0 || w.ngrp > 2 || (g_c3_dbg & 16)) { w.nfull = (N + 15) / 16; w.ngrp = 0; }
+  if (w.nfull == 0 || w.ngrp > 2 || (g_c3_dbg & (16 | 128))) { w.nfull = (N + 15) / 16; w.ngrp = 0; }   // 128: timing study
   return w;
 }
 

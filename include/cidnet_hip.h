@@ -136,7 +136,8 @@ int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, con
  * Y[b][m] = sum_{k,tap} Wt[m*w_ms + k*w_ks + tap'] * Xpad[b][k] ; forward: w_ms=9K, w_ks=9, flip=0;
  * data gradient of the zero-pad conv: X=dY, M=Cin, K=Cout, w_ms=9, w_ks=9*Cin, flip=1. */
 /* timing-study switches for cidnet_conv3x3 (1 no stores, 2 no window prefetch loads, 4 constant weights,
- * 8 MFMA path even for thin (<= 4 channel) layers, 16 padded 16-row tiles instead of 4x4x1 row groups) */
+ * 8 MFMA path even for thin (<= 4 channel) layers, 16 padded 16-row tiles instead of 4x4x1 row groups,
+ * 128 weight gradient: input-channel remainder as a padded 16-column tile instead of the 4-column-group launch) */
 void cidnet_debug_c3_flags(int flags);
 int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
                    int replicate, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);

@@ -40,5 +40,5 @@ def run_wg(B, M, N, H, W, flags, iters=10):
     return us, 2.0 * 9 * M * N * H * W * B / (us * 1e-6) / 1e12
 
 for sh in [(8, 36, 36, 400, 600), (8, 36, 36, 200, 300), (8, 72, 36, 200, 300), (8, 144, 72, 100, 150), (8, 36, 72, 100, 150), (8, 72, 144, 50, 75)]:
-    a, p, nm, ne = run_wg(*sh, flags=0), run_wg(*sh, flags=16), run_wg(*sh, flags=32), run_wg(*sh, flags=64)
-    print(f"wgrad {sh}: {a[0]:7.1f} us {a[1]:5.1f} TF | padded tiles {p[0]:7.1f} us {p[1]:5.1f} TF | no main loop {nm[0]:7.1f} | no epilogue {ne[0]:7.1f}")
+    a, p, nm, ne, pn = run_wg(*sh, flags=0), run_wg(*sh, flags=16), run_wg(*sh, flags=32), run_wg(*sh, flags=64), run_wg(*sh, flags=128)
+    print(f"wgrad {sh}: {a[0]:7.1f} us {a[1]:5.1f} TF | padded tiles {p[0]:7.1f} us {p[1]:5.1f} TF | no main loop {nm[0]:7.1f} | no epilogue {ne[0]:7.1f} | N remainder as a padded tile {pn[0]:7.1f}")
