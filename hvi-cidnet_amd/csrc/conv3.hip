@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
             accl[6 + dx][lg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MT + lg][e], w2.v[e + dx], accl[6 + dx][lg], 0, 0, 0);
           }
         }
-      __builtin_amdgcn_sched_barrier(0);
+      // (no fence behind the burst here: letting the scheduler sink the window rotation into its tail measured 1-3 % faster)
       w0 = w1; w1 = w2;
     }
   }
