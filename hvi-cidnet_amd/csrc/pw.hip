@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 // Requires HW % 4 == 0 (streaming addressing, see pw_conv_kernel) -- the ragged tail tile of other
 // planes goes through pw_conv_kernel<.., TAIL = true>.
 template <int MT, int EPI, int KS>
-__global__ __launch_bounds__(kThreads) void pw_conv_rega_kernel(PwArgs a) {
+__global__ __launch_bounds__(kThreads, (EPI == 2 ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
   constexpr int MB = 16 * MT;
   // prefetch distance in k-steps: a whole 9-step tile ahead (~4600 MFMA cycles per wave, and the
   // co-resident wave doubles it) -- HBM latency under load is several thousand cycles
@@ -292,14 +292,30 @@ __global__ __launch_bounds__(kThreads) void pw_conv_rega_kernel(PwArgs a) {
   const long tile_end = min(tile_beg + a.tpb, (long)a.ntile_lim);
   const int klast = a.K - 1;
 
+  // The block's weight panel goes through LDS once: read from global along the unit-stride axis of the weight tensor
+  // (coalesced), then each lane picks its KS x MT fragments.  Reading the fragments straight from global is a gather
+  // of 64 separate 4-byte requests per load -- 11 us of address processing per block on the 72 -> 382 layer, more
+  // than a pixel tile's MFMA time (tools/micro_pw.py, target-blocks sweep).
+  constexpr int KP = 4 * KS, LDW = KP + 1;       // odd row stride: conflict-free column writes and fragment reads
+  __shared__ float Ws[MB * LDW];
+  {
+    constexpr int TOT = MB * KP, NIT = (TOT + kThreads - 1) / kThreads;
+    const bool k_contig = a.w_ks == 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * kThreads + (int)threadIdx.x;
+      const int mm = k_contig ? idx / KP : idx % MB, kk = k_contig ? idx % KP : idx / MB;
+      float v = 0.f;
+      if (idx < TOT && m0 + mm < a.M && kk < a.K) v = Wb[(long)(m0 + mm) * a.w_ms + (long)kk * a.w_ks];
+      if (idx < TOT) Ws[mm * LDW + kk] = v;
+    }
+  }
+  __syncthreads();
   float areg[KS][MT];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + mt * 16 + c, k = 4 * ks + j;
-      areg[ks][mt] = (m < a.M && k < a.K) ? Wb[(long)m * a.w_ms + (long)k * a.w_ks] : 0.f;
-    }
+    for (int mt = 0; mt < MT; ++mt) areg[ks][mt] = Ws[(mt * 16 + c) * LDW + 4 * ks + j];
 
   auto xrow = [&](long tile, int ks) -> const float* {
     const long p0 = tile * 256 + wave * 64 + 4 * c;
@@ -377,7 +393,11 @@ template <int MT, int EPI, int KS>
 int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   constexpr int MB = 16 * MT;
   const long mblocks = (a.M + MB - 1) / MB;
-  const long target = g_pw_target_blocks;
+  // 512 blocks are resident (two per CU).  Store-heavy, bandwidth-bound layers (M >= 2K, below ~25 FLOP/B: e.g. the
+  // 36 -> 190 project_in at 200x300) run 15 % faster as about two rounds of shorter blocks; read-heavy and MFMA-bound
+  // ones prefer one round (tools/micro_pw.py target-blocks sweeps)
+  const bool store_heavy = a.M >= 2 * a.K && (long)a.M * a.K < 50L * (a.M + a.K);
+  const long target = g_pw_target_set ? g_pw_target_blocks : (store_heavy ? 1024 : 512);
   long tpb = (nstream * mblocks * B + target - 1) / target;
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   a.tpb = (int)tpb;
