@@ -620,10 +620,10 @@ int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
     // re-reads the whole input, so take the largest tile count that pads at most one tile in total
     // (tools/sweep_pw.py: M=72 runs 88 us with 3+2(+1 padded) tiles, 120 us as five single-tile blocks)
     const int mtmax = ks <= 9 ? 4 : 3;
-    int best = 1;
-    for (int mt = mtmax; mt >= 1; --mt) {
+    int best = 1, best_pad = 1 << 30;
+    for (int mt = mtmax; mt >= 1; --mt) {        // least padding among those, the larger tile count on a tie (M = 36: 3, not 4)
       const int pad = ((T + mt - 1) / mt) * mt;
-      if (pad <= T + 1) { best = mt; break; }
+      if (pad <= T + 1 && pad < best_pad) { best = mt; best_pad = pad; }
     }
     MT = best;
     if (g_pw_force_mt >= 1 && g_pw_force_mt <= mtmax) MT = g_pw_force_mt;
