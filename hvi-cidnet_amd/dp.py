@@ -71,13 +71,15 @@ class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, n_buckets: int = 4, loss_fn: Optional[Callable] = None,
                  process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = True, use_graph: bool = False,
-                 max_steps_in_flight: int = 2):
+                 max_steps_in_flight: int = 3):
         self.model = model
         # The host enqueues a step in ~13 ms and the GPU runs it in ~31 ms: left alone, the host is thousands of
         # launches ahead after ten steps, and the HIP runtime then blocks one launch for 0.5-2.5 s with the GPU idle
         # (seen in 5 of 8 bench runs, always around the 10th step; a watchdog stack dump showed the autograd thread
         # inside a kernel launch).  The trainer therefore waits for the step before the previous one before it
         # enqueues a new one: the queue never holds more than `max_steps_in_flight` steps, the GPU never starves.
+        # Three, not two: the stall needed ~5.5 steps (4000+ launches) in flight, and a queue of two steps (62 ms of work)
+        # is drained by an ordinary 65 ms host hiccup (seen once under torch.distributed.run: 218 instead of 250 img/s).
         self.max_steps_in_flight = max(1, int(max_steps_in_flight))
         self._step_events = []
         self.loss_fn = loss_fn or _default_loss
