@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 // Requires HW % 4 == 0 (streaming addressing, see pw_conv_kernel) -- the ragged tail tile of other
 // planes goes through pw_conv_kernel<.., TAIL = true>.
 template <int MT, int EPI, int KS>
-__global__ __launch_bounds__(kThreads, (EPI == 2 ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
+__global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
   constexpr int MB = 16 * MT;
   // prefetch distance in k-steps: a whole 9-step tile ahead (~4600 MFMA cycles per wave, and the
   // co-resident wave doubles it) -- HBM latency under load is several thousand cycles
