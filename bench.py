@@ -111,10 +111,6 @@ def main():
 
     import hvi_cidnet_amd as P
     from hvi_cidnet_amd.dp import DataParallelTrainer
-    if os.environ.get("CIDNET_PW_FLAGS"):            # timing studies only (see include/cidnet_hip.h)
-        from hvi_cidnet_amd._lib import lib as _lib
-        _lib().raw("cidnet_debug_pw_flags")(int(os.environ["CIDNET_PW_FLAGS"]))
-
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream

@@ -19,6 +19,7 @@ ERR_NAMES = {-1: "CIDNET_ERR_ARG (null pointer / non-positive size)", -2: "CIDNE
 def parse_header(path: str = HEADER):
     """-> {name: (restype, [(argtype, argname), ...])} for every prototype in the header."""
     text = open(path).read()
+    text = re.sub(r"#ifdef CIDNET_DEBUG.*?#endif", "", text, flags=re.S)    # timing-study switches: debug builds only
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     out = {}

@@ -29,7 +29,11 @@ constexpr int kThreads = 256;
 constexpr int kR = 2;      // output rows per wave
 constexpr int kKC = 36;    // input channels staged per chunk (9 k-groups)
 constexpr int kStageBatch = 6;   // 16-byte weight loads a thread keeps in flight while staging the panel
-int g_c3_dbg = 0;
+#ifdef CIDNET_DEBUG
+int g_c3_dbg = 0;          // timing-study switches (cidnet_debug_c3_flags); the shipped library has no mutable state
+#else
+constexpr int g_c3_dbg = 0;
+#endif
 
 struct C3Args {
   const float* X; long x_bs;
@@ -857,7 +861,9 @@ using namespace cidnet;
 
 extern "C" {
 
+#ifdef CIDNET_DEBUG
 void cidnet_debug_c3_flags(int flags) { g_c3_dbg = flags; }
+#endif
 
 #ifdef C3_TIMING
 // copies the per-block phase cycles [stage, k loops, epilogues, total] of the last conv3_kernel launch to the host

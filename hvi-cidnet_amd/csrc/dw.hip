@@ -60,7 +60,11 @@ __device__ __forceinline__ Item decode_item(long planes, Tiling tl, int W) {
 // (`min_lanes`), and in the block-per-plane kernels a plane's items are rounded up to whole waves.  Cost model:
 // lane-iterations = lanes (rounded to waves if per_plane) x (rows + halo); heights above kMinRows are only
 // taken while the launch keeps min_lanes lanes.
-int g_dw_force_rows = 0;     // timing studies only (cidnet_debug_dw_rows)
+#ifdef CIDNET_DEBUG
+int g_dw_force_rows = 0;     // timing studies only (cidnet_debug_dw_rows; -DCIDNET_DEBUG builds)
+#else
+constexpr int g_dw_force_rows = 0;
+#endif
 
 inline Tiling pick_tiling(long planes, int H, int W, int halo, long min_lanes, bool per_plane) {
   const int nx4 = (W + 3) >> 2;
@@ -531,7 +535,9 @@ using namespace cidnet;
 
 extern "C" {
 
+#ifdef CIDNET_DEBUG
 void cidnet_debug_dw_rows(int rows) { g_dw_force_rows = rows; }
+#endif
 
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend, float* out, int flip,
                  int B, int C, int H, int W, void* stream) {

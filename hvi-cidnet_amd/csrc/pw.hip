@@ -21,10 +21,18 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kDepth = 4;     // k-steps of the activation operand prefetched per wave
-int g_pw_force_mt = 0;          // timing studies: force the channel-tile count per block
+// timing-study switches exist only in -DCIDNET_DEBUG builds; the shipped library has no mutable process state
+#ifdef CIDNET_DEBUG
+int g_pw_force_mt = 0;          // force the channel-tile count per block
 long g_pw_target_blocks = 512;   // blocks a launch aims for (each walks several pixel tiles)
 bool g_pw_target_set = false;    // cidnet_debug_pw_flags overrode it
-int g_pw_dbg = 0;             // timing-study switches (cidnet_debug_pw_flags): 1 no stores, 2 no K loop, 4 LDS kernel only
+int g_pw_dbg = 0;             // cidnet_debug_pw_flags: 1 no stores, 2 no K loop, 4 LDS kernel only
+#else
+constexpr int g_pw_force_mt = 0;
+constexpr long g_pw_target_blocks = 512;
+constexpr bool g_pw_target_set = false;
+constexpr int g_pw_dbg = 0;
+#endif
 
 struct PwArgs {
   const float* X; long x_bs;
@@ -787,7 +795,11 @@ inline int pick_tiles(int dim, int maxt) {   // tiles per block for a dimension 
   return (T + nblk - 1) / nblk;
 }
 
+#ifdef CIDNET_DEBUG
 int g_wg_force_pch = 0;          // timing studies (cidnet_debug_pw_flags bit 7 set: bits 8.. = pixels per block / 128)
+#else
+constexpr int g_wg_force_pch = 0;
+#endif
 
 // Pixels per block of the weight-gradient kernel (multiple of 128 = one step of the block's four waves).  A block costs
 // its pixel steps plus about 6 steps' worth of prologue / LDS reduction / slab write, and 256 CUs hold 512 blocks at a
@@ -815,6 +827,7 @@ using namespace cidnet;
 
 extern "C" {
 
+#ifdef CIDNET_DEBUG
 void cidnet_debug_pw_flags(int flags) {
   g_pw_dbg = flags & 0xFF;
   g_pw_force_mt = (flags >> 28) & 7;
@@ -823,6 +836,7 @@ void cidnet_debug_pw_flags(int flags) {
   g_pw_target_set = ((flags >> 8) & 0xFFFFF) != 0;
   g_pw_target_blocks = g_pw_target_set ? (flags >> 8) & 0xFFFFF : 512;
 }
+#endif
 
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
                    const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {

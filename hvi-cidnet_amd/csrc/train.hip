@@ -42,6 +42,23 @@ __global__ void l1_finish_kernel(const float* __restrict__ part, int n, float in
   if (threadIdx.x == 0) loss[0] = s * inv_n;
 }
 
+// y = x * s[0] * mult: the upstream scalar of a loss's backward applied on the device (no host read of s)
+__global__ __launch_bounds__(kThreads) void scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float mult,
+                                                         float* __restrict__ y, long n) {
+  const float f = (s ? s[0] : 1.f) * mult;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = load4u(x + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= f;
+    store4u(y + 4 * i, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    y[i] = x[i] * f;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                         float wd, float bc1, float bc2_sqrt, float gscale) {
@@ -76,6 +93,15 @@ int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, 
   hipLaunchKernelGGL(l1_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, out, gt, grad, ws, n, inv_n);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, grid, inv_n, loss);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_scale(const float* x, const float* s, float mult, float* y, long n, void* stream) {
+  CIDNET_CHECK_ARG(x && y && n > 0);
+  long g = ((n + 3) / 4 + kThreads - 1) / kThreads;
+  const int grid = (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+  hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, x, s, mult, y, n);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -171,6 +171,7 @@ class DataParallelTrainer:
         self._pending = [0] * len(self.buckets)
         # 4) gradients written in place by the HIP backward kernels (single-use parameters only)
         multi = [p.data_ptr() for p in live if id(p) in multi_ids]      # pointers AFTER re-homing into flat_p
+        self._multi_ids = multi_ids
         if self.use_hip:
             from . import ops
             ops.set_grad_arena(self.flat_p, self.flat_g, exclude_ptrs=multi)
@@ -190,7 +191,12 @@ class DataParallelTrainer:
         off, n = self._slices[id(p)]
         slot = self.flat_g[off:off + n]
         if p.grad.data_ptr() != slot.data_ptr():
-            slot.copy_(p.grad.reshape(-1))          # multi-use parameters / anything autograd cloned
+            # multi-use parameters (summed by autograd on the branch streams) -- or a single-use gradient autograd
+            # cloned instead of stealing: that one may still be in flight on the weight-gradient stream, so the copy
+            # waits for it (never seen in practice; without the wait it would read a stale gradient)
+            if self.use_hip and self.wgrad_stream and p.grad.is_cuda and id(p) not in getattr(self, "_multi_ids", ()):
+                self._join_wgrad_stream()
+            slot.copy_(p.grad.reshape(-1))
         p.grad = None                               # the arena is the single home of gradients
         bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1

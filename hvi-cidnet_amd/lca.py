@@ -49,8 +49,8 @@ class IEL(nn.Module):
         self.Tanh = nn.Tanh()
 
     def forward(self, x, residual=None):
-        return ops.IELFn.apply(x, residual, self.project_in.weight, self.dwconv.weight, self.dwconv1.weight,
-                               self.dwconv2.weight, self.project_out.weight)
+        ws = (self.project_in.weight, self.dwconv.weight, self.dwconv1.weight, self.dwconv2.weight, self.project_out.weight)
+        return ops.IELFn.apply(x, residual, *ws, ops.needs_grad(x, residual, *ws))
 
 
 class HV_LCA(nn.Module):

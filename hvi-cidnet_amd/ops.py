@@ -13,6 +13,13 @@ from ._lib import lib
 _vp = ctypes.c_void_p
 
 
+def needs_grad(*ts):
+    """True when a backward pass can follow: decided by the MODULE before .apply(), because inside
+    Function.forward grad mode is always off and ctx.needs_input_grad stays True for requires_grad
+    parameters even under torch.no_grad()."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 def _check(*ts):
     for t in ts:
         if t is None:
@@ -424,7 +431,7 @@ class IELFn(torch.autograd.Function):
     """Reference: IEL.forward (net/LCA.py:60-67); `res` is the residual of I_LCA (LCA.py:92)."""
 
     @staticmethod
-    def forward(ctx, xn, res, w_in, w_dw, w_dw1, w_dw2, w_out):
+    def forward(ctx, xn, res, w_in, w_dw, w_dw1, w_dw2, w_out, train=True):
         _check(xn, res, w_in, w_dw, w_dw1, w_dw2, w_out)
         xn = _c(xn)
         res = _c(res) if res is not None else None
@@ -434,8 +441,7 @@ class IELFn(torch.autograd.Function):
         dev = xn.device
         pin = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32)
         pw_conv(xn, 0, C * HW, w_in, 0, 0, C, 1, pin, 0, 2 * h * HW, B, 2 * h, C, HW)
-        train = any(ctx.needs_input_grad)               # inference: u (read only by the backward) is not stored
-        u = torch.empty_like(pin) if train else None
+        u = torch.empty_like(pin) if train else None      # inference: u (read only by the backward) is not stored
         gate = torch.empty((B, h, H, W), device=dev, dtype=torch.float32)
         lib().call("cidnet_iel_dw_gate_fwd", _p(pin), _p(w_dw), _p(w_dw1), _p(w_dw2), _p(u) if train else None, _p(gate), B, h, H, W,
                    _stream())
@@ -473,7 +479,7 @@ class IELFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dxn = torch.empty_like(xn)
             pw_conv(dpin, 0, 2 * h * HW, w_in, 0, 0, 1, C, dxn, 0, C * HW, B, C, 2 * h, HW)
-        return dxn, (go if ctx.has_res else None), g_win, g_dw, g_dw1, g_dw2, g_wout
+        return dxn, (go if ctx.has_res else None), g_win, g_dw, g_dw1, g_dw2, g_wout, None
 
 
 # --------------------------------------------------------------------------------------------
@@ -484,14 +490,14 @@ class DownFn(torch.autograd.Function):
     (align_corners=True) -> PReLU."""
 
     @staticmethod
-    def forward(ctx, x, w, slope):
+    def forward(ctx, x, w, slope, train=True):
         _check(x, w, slope)
         x = _c(x)
         B, Ci, H, W = x.shape
         Co = w.shape[0]
         t = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
         conv3x3(x, w, t, B, Co, Ci, H, W, 9 * Ci, 9)
-        train = any(ctx.needs_input_grad)               # inference: the pre-activation (read by the backward) is not stored
+        # train=False (inference): the pre-activation (read only by the backward) is not stored
         out = torch.empty((B, Co, H // 2, W // 2), device=x.device, dtype=torch.float32)
         pre = torch.empty_like(out) if train else None
         lib().call("cidnet_down_prelu_fwd", _p(t), _p(slope), _p(pre), _p(out), B, Co, H, W, _stream())
@@ -514,7 +520,7 @@ class DownFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             conv3x3(dt, w, dx, B, Ci, Co, H, W, 9, 9 * Ci, flip=True)
-        return dx, gw, dslope
+        return dx, gw, dslope, None
 
 
 class DownResFn(torch.autograd.Function):
@@ -525,7 +531,7 @@ class DownResFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, slope):
-        out = DownFn.forward(ctx, x, w, slope)
+        out = DownFn.forward(ctx, x, w, slope, True)
         return out, x.view_as(x)
 
     @staticmethod
@@ -536,7 +542,7 @@ class DownResFn(torch.autograd.Function):
         if go is None:
             return gres, None, None
         if gres is None or min(Ci, Co) <= 4:
-            dx, gw, dslope = DownFn.backward(ctx, go)
+            dx, gw, dslope, _ = DownFn.backward(ctx, go)
             if gres is not None and dx is not None:
                 dx = dx + gres
             return dx, gw, dslope
@@ -556,7 +562,7 @@ class UpFn(torch.autograd.Function):
     applied BEFORE the (linear) bilinear map, at a quarter of the pixels; no concat is materialised."""
 
     @staticmethod
-    def forward(ctx, x, skip, w, w_up, slope):
+    def forward(ctx, x, skip, w, w_up, slope, train=True):
         _check(x, skip, w, w_up, slope)
         x, skip = _c(x), _c(skip)
         B, Ci, h, wd = x.shape
@@ -568,7 +574,6 @@ class UpFn(torch.autograd.Function):
         conv3x3(x, w, t, B, Co, Ci, h, wd, 9 * Ci, 9)
         z = torch.empty_like(t)
         pw_conv(t, 0, Co * h * wd, w_up, 0, 0, 2 * Co, 1, z, 0, Co * h * wd, B, Co, Co, h * wd)
-        train = any(ctx.needs_input_grad)
         out = torch.empty_like(skip)
         pre = torch.empty_like(skip) if train else None
         lib().call("cidnet_pw_conv_up_prelu", _p(skip), Co * 4 * h * wd, _po(w_up, Co), 2 * Co, 1, _p(z), _p(slope), _p(out),
@@ -602,7 +607,7 @@ class UpFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             conv3x3(dt, w, dx, B, Ci, Co, h, wd, 9, 9 * Ci, flip=True)
-        return dx, dskip, gw, g_wup, dslope
+        return dx, dskip, gw, g_wup, dslope, None
 
 
 class RepConv3x3Fn(torch.autograd.Function):
@@ -685,14 +690,24 @@ class AddFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # training-step pieces: L1 loss (loss + gradient in one pass) and fused flat Adam
 # --------------------------------------------------------------------------------------------
+def _scaled(x, g, mult):
+    """x * g * mult with the 0-dim upstream gradient g read on the device"""
+    y = torch.empty_like(x)
+    g = g.to(torch.float32).reshape(1).contiguous()
+    lib().call("cidnet_scale", _p(x), _p(g), _f(mult), _p(y), x.numel(), _stream())
+    return y
+
+
 class L1LossFn(torch.autograd.Function):
-    """mean(|out - gt|): reference L1Loss (loss/losses.py:10-20, loss_utils.py l1_loss, reduction='mean')."""
+    """mean(|out - gt|): reference L1Loss (loss/losses.py:10-20, loss_utils.py l1_loss, reduction='mean').
+    Differentiable in both arguments: train.py:62 does not detach gt_hvi = model.HVIT(gt_rgb), so the HVI-space
+    terms send gradient to density_k through the target as well."""
 
     @staticmethod
     def forward(ctx, out, gt):
         _check(out, gt)
         out, gt = _c(out), _c(gt)
-        grad = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        grad = torch.empty_like(out) if any(ctx.needs_input_grad) else None
         loss = torch.empty((), device=out.device, dtype=torch.float32)
         n = _raw("cidnet_l1_loss_ws_floats")
         ws = _ws(n, out.device)
@@ -703,19 +718,19 @@ class L1LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None        # g is the scalar d(total)/d(loss); 1.0 in the benchmark step
+        # g is the scalar d(total)/d(loss); 1.0 in the benchmark step
+        return (_scaled(grad, g, 1.0) if ctx.needs_input_grad[0] else None,
+                _scaled(grad, g, -1.0) if ctx.needs_input_grad[1] else None)
 
 
 class SSIMLossFn(torch.autograd.Function):
     """(1 - mean(ssim_map(img1, img2))) * weight: reference SSIM.forward (loss/losses.py:166-190) with map_ssim
-    (loss/loss_utils.py:125-145); 11x11 Gaussian window, zero padding.  Gradient to img1 only (img2 = ground truth)."""
+    (loss/loss_utils.py:125-145); 11x11 Gaussian window, zero padding.  The SSIM map is symmetric in its two images,
+    so the gradient wrt img2 (needed when img2 = HVIT(gt) depends on density_k) is the img1 formula with the roles
+    swapped: one more forward pass of the kernel with (img2, img1), only when that gradient is requested."""
 
     @staticmethod
-    def forward(ctx, img1, img2, weight):
-        _check(img1, img2)
-        img1, img2 = _c(img1), _c(img2)
-        if img1.shape != img2.shape or img1.dim() != 4:
-            raise RuntimeError("SSIM: img1 and img2 must be (B,C,H,W) tensors of the same shape")
+    def _fwd(img1, img2, weight):
         B, C, H, W = img1.shape
         dA, dB, dC = torch.empty_like(img1), torch.empty_like(img1), torch.empty_like(img1)
         loss = torch.empty((), device=img1.device, dtype=torch.float32)
@@ -723,6 +738,15 @@ class SSIMLossFn(torch.autograd.Function):
         ws = _ws(n, img1.device)
         lib().call("cidnet_ssim_fwd", _p(img1), _p(img2), _f(weight), _p(loss), _p(dA), _p(dB), _p(dC), _p(ws), ws.numel(), B, C, H, W,
                    _stream())
+        return loss, dA, dB, dC
+
+    @staticmethod
+    def forward(ctx, img1, img2, weight):
+        _check(img1, img2)
+        img1, img2 = _c(img1), _c(img2)
+        if img1.shape != img2.shape or img1.dim() != 4:
+            raise RuntimeError("SSIM: img1 and img2 must be (B,C,H,W) tensors of the same shape")
+        loss, dA, dB, dC = SSIMLossFn._fwd(img1, img2, weight)
         ctx.save_for_backward(img1, img2, dA, dB, dC)
         ctx.weight = float(weight)
         return loss
@@ -732,13 +756,20 @@ class SSIMLossFn(torch.autograd.Function):
         img1, img2, dA, dB, dC = ctx.saved_tensors
         B, C, H, W = img1.shape
         g = g.to(torch.float32).reshape(1).contiguous()
-        gx = torch.empty_like(img1)
-        lib().call("cidnet_ssim_bwd", _p(img1), _p(img2), _p(dA), _p(dB), _p(dC), _p(g), _f(ctx.weight), _p(gx), B, C, H, W, _stream())
-        return gx, None, None
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(img1)
+            lib().call("cidnet_ssim_bwd", _p(img1), _p(img2), _p(dA), _p(dB), _p(dC), _p(g), _f(ctx.weight), _p(gx), B, C, H, W, _stream())
+        if ctx.needs_input_grad[1]:
+            _, eA, eB, eC = SSIMLossFn._fwd(img2, img1, ctx.weight)
+            gy = torch.empty_like(img2)
+            lib().call("cidnet_ssim_bwd", _p(img2), _p(img1), _p(eA), _p(eB), _p(eC), _p(g), _f(ctx.weight), _p(gy), B, C, H, W, _stream())
+        return gx, gy, None
 
 
 class EdgeLossFn(torch.autograd.Function):
-    """mean((laplacian(x) - laplacian(y))^2) * weight: reference EdgeLoss.forward (loss/losses.py:41-65).  Gradient to x only."""
+    """mean((laplacian(x) - laplacian(y))^2) * weight: reference EdgeLoss.forward (loss/losses.py:41-65).  The loss
+    depends on x - y only (the Laplacian is linear), so d/dy = -d/dx."""
 
     @staticmethod
     def forward(ctx, x, y, weight):
@@ -765,7 +796,11 @@ class EdgeLossFn(torch.autograd.Function):
         n = _raw("cidnet_edge_ws_floats", B, C, H, W)
         ws = _ws(n, lap.device)
         lib().call("cidnet_edge_bwd", _p(lap), _p(g), _f(ctx.weight), _p(gx), _p(ws), ws.numel(), B, C, H, W, _stream())
-        return gx, None, None
+        gy = None
+        if ctx.needs_input_grad[1]:
+            gy = torch.empty_like(gx)
+            lib().call("cidnet_scale", _p(gx), None, _f(-1.0), _p(gy), gx.numel(), _stream())
+        return (gx if ctx.needs_input_grad[0] else None), gy, None
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

@@ -51,7 +51,8 @@ class NormDownsample(nn.Module):
             nn.UpsamplingBilinear2d(scale_factor=scale))
 
     def forward(self, x):
-        x = ops.DownFn.apply(x, self.down[0].weight, self.prelu.weight)
+        ws = (self.down[0].weight, self.prelu.weight)
+        x = ops.DownFn.apply(x, *ws, ops.needs_grad(x, *ws))
         return self.norm(x) if self.use_norm else x
 
     def forward_res(self, x):
@@ -80,5 +81,6 @@ class NormUpsample(nn.Module):
         self.up = nn.Conv2d(out_ch * 2, out_ch, kernel_size=1, stride=1, padding=0, bias=False)
 
     def forward(self, x, y):
-        x = ops.UpFn.apply(x, y, self.up_scale[0].weight, self.up.weight, self.prelu.weight)
+        ws = (self.up_scale[0].weight, self.up.weight, self.prelu.weight)
+        x = ops.UpFn.apply(x, y, *ws, ops.needs_grad(x, y, *ws))
         return self.norm(x) if self.use_norm else x

@@ -82,9 +82,11 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
  *   A_b[m][k] = Wt[b*w_bs + m*w_ms + k*w_ks]   (w_bs = 0: shared weights; forward: w_ms=K,w_ks=1;
  *   data gradient: w_ms=1, w_ks=<Cin>), X[b] at X + b*x_bs with channel stride HW (same for Y, R),
  *   so channel slices of wider tensors can be read / written in place.  R may alias Y. */
+#ifdef CIDNET_DEBUG
 /* timing-study switches for cidnet_pw_conv (bit0: no stores, bit1: no K loop; bit7: force the weight-gradient
- * kernel to (flags >> 8) * 128 pixels per block); 0 = production */
+ * kernel to (flags >> 8) * 128 pixels per block); 0 = production.  Only in -DCIDNET_DEBUG builds. */
 void cidnet_debug_pw_flags(int flags);
+#endif
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
                    float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
                    void* stream);
@@ -103,8 +105,10 @@ int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, floa
 /* ---- K5 / K8: depthwise 3x3 (zero pad) and the IEL gate  (net/LCA.py:14,16,53-55,62-65) --------
  * out = dw3x3(in) [+ addend]; channel c uses w1[c] if c < csplit else w2[c-csplit] (weights (.,1,3,3));
  * flip != 0 applies the 180-degree rotated taps (= data gradient of the forward). */
+#ifdef CIDNET_DEBUG
 /* timing-study switch: force the strip height of the depthwise / gate kernels (0 = automatic) */
 void cidnet_debug_dw_rows(int rows);
+#endif
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend,
                  float* out, int flip, int B, int C, int H, int W, void* stream);
 long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W);
@@ -135,10 +139,12 @@ int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, con
  * (net/transformer_utils.py:39,58 zero pad; net/CIDNet.py:21-24,32-35,39-42,50-53 replicate pad)
  * Y[b][m] = sum_{k,tap} Wt[m*w_ms + k*w_ks + tap'] * Xpad[b][k] ; forward: w_ms=9K, w_ks=9, flip=0;
  * data gradient of the zero-pad conv: X=dY, M=Cin, K=Cout, w_ms=9, w_ks=9*Cin, flip=1. */
+#ifdef CIDNET_DEBUG
 /* timing-study switches for cidnet_conv3x3 (1 no stores, 2 no window prefetch loads, 4 constant weights,
  * 8 MFMA path even for thin (<= 4 channel) layers, 16 padded 16-row tiles instead of 4x4x1 row groups,
  * 128 weight gradient: input-channel remainder as a padded 16-column tile instead of the 4-column-group launch) */
 void cidnet_debug_c3_flags(int flags);
+#endif
 int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
                    int replicate, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
 /* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
@@ -192,6 +198,10 @@ int cidnet_sum_rows(const float* in, int n_red, long n, float* out, void* stream
 long cidnet_l1_loss_ws_floats(void);
 int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, float* ws,
                    long ws_floats, long n, void* stream);
+/* y = x * s[0] * mult (s: device scalar, may be null = 1): the upstream factor d(total)/d(loss) of a loss's
+ * backward, and the sign flip that gives the gradient wrt the target (train.py:62: gt_hvi = model.HVIT(gt_rgb)
+ * is NOT detached, so density_k receives gradient through the target of every HVI-space term) */
+int cidnet_scale(const float* x, const float* s, float mult, float* y, long n, void* stream);
 /* SSIM loss ("next" row f1): SSIM.forward, loss/losses.py:166-190 with map_ssim, loss/loss_utils.py:125-145:
  * 11x11 Gaussian window (sigma 1.5), zero padding 5, depthwise; loss = (1 - mean(ssim_map)) * weight (1 float on the
  * device).  dA/dB/dC (B,C,H,W each) are the per-pixel derivative maps the backward filters; ws: block partials.

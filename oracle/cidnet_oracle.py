@@ -620,3 +620,15 @@ def synthetic_batch(seed: int, shape, quantised: bool = False) -> torch.Tensor:
     else:
         a = rng.random(shape, dtype=np.float32)
     return torch.from_numpy(a)
+
+
+def grad_fingerprint(t: torch.Tensor, max_sample: int = 2048):
+    """Compact fixture form of a large tensor: (sums, sample).  sums = [sum, sum|.|, dot with a fixed
+    non-periodic weight vector] in fp64 (the dot catches permuted / shifted elements that the plain sums
+    miss); sample = every stride-th element of the flattened tensor (at most `max_sample`).  Used by
+    oracle/gen_golden.py to store full-size gradients compactly and by the GPU parity tests to compare."""
+    f = t.detach().reshape(-1).double().cpu()
+    w = torch.cos(torch.arange(f.numel(), dtype=torch.float64) * 0.7390851332151607)
+    sums = torch.stack([f.sum(), f.abs().sum(), (f * w).sum()])
+    stride = max(1, -(-f.numel() // max_sample))
+    return sums, f[::stride].float(), stride

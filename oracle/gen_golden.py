@@ -72,7 +72,7 @@ class KinkMargin:
         return self.margin
 
 
-def pick_input_seed(make_model, shape, run, first=51, tries=40):
+def pick_input_seed(make_model, shape, run, first=51, tries=40, min_ok=1e-6):
     """the input seed among first, first+100, ... whose forward stays farthest from every kink"""
     best = (-1.0, None)
     for t in range(tries):
@@ -86,7 +86,7 @@ def pick_input_seed(make_model, shape, run, first=51, tries=40):
         if best[0] >= KinkMargin.MIN_MARGIN:
             break
     print(f"  input seed {best[1]}: kink margin {best[0]:.2e}")
-    assert best[0] >= 1e-6, "no input seed with a usable kink margin"
+    assert best[0] >= min_ok, "no input seed with a usable kink margin"
     return best[1], best[0]
 
 
@@ -547,6 +547,131 @@ def gen_lr_schedule():
     print("wrote lr_schedule.npz")
 
 
+def _store_grads(out, tag, named_grads, full_names=(), small=600):
+    """fingerprint (sums + strided sample) of every gradient tensor; full tensors for the small ones and
+    for `full_names`"""
+    for n, g in named_grads:
+        sums, sample, stride = O.grad_fingerprint(g, 512)
+        out[f"{tag}_gfp.{n}"] = sums.numpy()
+        out[f"{tag}_gs.{n}"] = sample.numpy()
+        if g.numel() <= small or n in full_names:
+            out[f"{tag}_g.{n}"] = g.detach().numpy()
+
+
+FULL_TENSORS = ("HVE_block1.down.0.weight", "IE_block2.down.0.weight", "HVE_block3.down.0.weight",
+                "HVD_block3.up_scale.0.weight", "ID_block2.up.weight", "HVD_block1.up_scale.0.weight",
+                "HV_LCA1.gdfn.project_in.weight", "I_LCA1.gdfn.project_out.weight", "HV_LCA2.ffn.q.weight",
+                "I_LCA3.ffn.kv.weight", "HV_LCA6.ffn.project_out.weight", "I_LCA6.gdfn.dwconv.weight",
+                "HV_LCA4.gdfn.dwconv1.weight", "I_LCA2.ffn.kv_dwconv.weight", "HVE_block0.1.weight", "ID_block0.1.weight")
+
+
+def gen_fullsize():
+    """BASELINE.json sizes through the imported reference:
+    (a) 1x3x400x600 forward + backward, full width, jittered parameters: output, loss, d(loss)/d(input) and a
+        fingerprint (sums + strided sample) of EVERY live gradient tensor, full tensors for one member of each
+        kernel family -- the benchmark's own tile shapes / multi-round grids / 75- and 150-pixel rows;
+    (b) 1x3x1024x1024 forward (configs[3] image size): strided output, checksums, count of black pixels;
+    (c) full-width (36/36/72/144, c/head = 18) MSSA and TNSM at 1x3x64x96, all gradients."""
+    out = {}
+    # ---- (a) ----
+    p = O.make_params(5)
+    m = RefCIDNet()
+    load_into(m, p)
+    shape = (1, 3, 400, 600)
+    x = O.synthetic_batch(161, shape).requires_grad_(True)
+    gt = O.synthetic_batch(162, shape)
+    km = KinkMargin(m)
+    yr = m(x)
+    km.loss(yr, gt)
+    loss = (yr - gt).abs().mean()
+    loss.backward()
+    print(f"  400x600 fwd+bwd through the reference done; kink margin {km.close():.2e}")
+    po = O.params_to(p, requires_grad=True)
+    xo = x.detach().clone().requires_grad_(True)
+    yo = O.cidnet_forward(po, xo)
+    (yo - gt).abs().mean().backward()
+    check_equal(yo, yr, "CIDNet fwd 1x3x400x600 (jittered params)")
+    check_equal(xo.grad, x.grad, "CIDNet d/dx 400x600", exact=False, tol=1e-5)
+    out["a_out_strided"] = yr.detach()[:, :, ::8, ::8].numpy()
+    yd = yr.detach().double()
+    out["a_out_sums"] = np.array([yd.sum().item(), yd.abs().sum().item(), (yd ** 2).sum().item()])
+    out["a_loss"] = np.float64(loss.item())
+    out["a_gx_strided"] = x.grad[:, :, ::8, ::8].numpy()
+    out["a_gx_fp"] = O.grad_fingerprint(x.grad)[0].numpy()
+    live = [(n, prm.grad) for n, prm in m.named_parameters() if prm.grad is not None]
+    assert len(live) == 191 - 13
+    worst = 0.0
+    for n, g in live:
+        worst = max(worst, (g - po[n].grad).abs().max().item() / max(g.abs().max().item(), 1e-30))
+    print(f"  ok  400x600 grads: worst rel-to-max diff oracle vs reference {worst:.2e}")
+    assert worst < 1e-4
+    _store_grads(out, "a", live, FULL_TENSORS)
+    # ---- (b) ----
+    p1 = O.make_params(5, jitter=False)
+    m = RefCIDNet()
+    load_into(m, p1)
+    x4 = O.synthetic_batch(171, (1, 3, 1024, 1024), quantised=True)
+    with torch.no_grad():
+        y4 = m(x4)
+        check_equal(O.cidnet_forward(p1, x4), y4, "CIDNet fwd 1x3x1024x1024")
+    out["b_out_strided"] = y4[:, :, ::32, ::32].numpy()
+    yd = y4.double()
+    out["b_out_sums"] = np.array([yd.sum().item(), yd.abs().sum().item(), (yd ** 2).sum().item()])
+    out["b_n_black"] = np.int64(((y4 == 0).all(1)).sum().item())
+    print(f"  1024x1024: {int(out['b_n_black'])} black pixels")
+    # ---- (c) ----
+    from net.CIDNet_MSSA import CIDNet as RefMSSA
+    from net.CIDNet_TNSM import CIDNet_TNSM as RefTNSM
+    shp = (1, 3, 64, 96)
+    pm = O.make_params(5, variant="mssa")
+
+    def make():
+        mm = RefMSSA()
+        load_into(mm, pm)
+        return mm
+    # ~1.5M PReLU / channel-max arguments at full width: margins of a few 1e-7 are the best any seed offers
+    seed, margin = pick_input_seed(make, shp, lambda mm, xx: mm(xx), tries=12, min_ok=1e-7)
+    m = make()
+    x, gt = O.synthetic_batch(seed, shp), O.synthetic_batch(seed + 1, shp)
+    yr = m(x)
+    (yr - gt).abs().mean().backward()
+    po = O.params_to(pm, requires_grad=True)
+    yo = O.cidnet_forward(po, x, variant="mssa")
+    (yo - gt).abs().mean().backward()
+    check_equal(yo, yr, "CIDNet_MSSA full width fwd")
+    out.update(mssa_x=x.numpy(), mssa_gt=gt.numpy(), mssa_out=yr.detach().numpy(), mssa_kink_margin=np.float64(margin))
+    g = [(n, prm.grad) for n, prm in m.named_parameters()]
+    assert all(t is not None for _, t in g) and len(g) == 197
+    worst = max((t - po[n].grad).abs().max().item() / max(t.abs().max().item(), 1e-30) for n, t in g)
+    print(f"  ok  full-width MSSA grads: worst rel-to-max diff oracle vs reference {worst:.2e}")
+    assert worst < 1e-4
+    _store_grads(out, "mssa", g)
+    pt = O.make_params(5, variant="tnsm")
+    m = RefTNSM()
+    load_into(m, pt)
+    m.train()
+    x, gt = O.synthetic_batch(51, shp), O.synthetic_batch(52, shp)
+    yr, fr = m(x)
+    ((yr - gt).abs().mean() + 0.1 * fr.mean()).backward()
+    po = O.params_to(pt, requires_grad=True)
+    yo, fo = O.cidnet_tnsm_forward(po, x)
+    ((yo - gt).abs().mean() + 0.1 * fo.mean()).backward()
+    check_equal(yo, yr, "CIDNet_TNSM full width fwd rgb")
+    check_equal(fo, fr, "CIDNet_TNSM full width fused noise")
+    out.update(tnsm_x=x.numpy(), tnsm_gt=gt.numpy(), tnsm_out=yr.detach().numpy(), tnsm_noise=fr.detach().numpy())
+    g = [(n, prm.grad) for n, prm in m.named_parameters() if prm.grad is not None]
+    dead = [n for n, prm in m.named_parameters() if prm.grad is None]
+    assert all(n.startswith(("I_LCA5.", "I_TNSM5.")) for n in dead), dead
+    out["tnsm_dead"] = np.array(dead)
+    _store_grads(out, "tnsm", g)
+    p64 = O.params_to(pt, dtype=torch.float64, requires_grad=True)
+    y64, f64 = O.cidnet_tnsm_forward(p64, x.double())
+    ((y64 - gt.double()).abs().mean() + 0.1 * f64.mean()).backward()
+    _store_grads(out, "tnsm64", [(n, v.grad.float()) for n, v in p64.items() if v.grad is not None])
+    np.savez_compressed(os.path.join(GOLD, "fullsize.npz"), **out)
+    print("wrote fullsize.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mssa":
         gen_mssa()
@@ -556,6 +681,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         gen_losses()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        gen_fullsize()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lr":
         gen_lr_schedule()
@@ -567,5 +695,6 @@ if __name__ == "__main__":
     gen_tnsm()
     gen_losses()
     gen_lr_schedule()
+    gen_fullsize()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

@@ -17,6 +17,16 @@ def test_header_parses_and_library_exports_every_symbol():
     assert _lib.lib().raw("cidnet_abi_version")() >= 1
 
 
+def test_shipped_library_has_no_debug_state():
+    """include/cidnet_hip.h promises stateless, re-entrant entry points: the timing-study switches
+    (cidnet_debug_*) exist only in -DCIDNET_DEBUG builds, never in the in-tree library"""
+    from hvi_cidnet_amd import _lib
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in ("cidnet_debug_pw_flags", "cidnet_debug_dw_rows", "cidnet_debug_c3_flags", "cidnet_debug_c3_phases"):
+        assert not hasattr(dll, name), f"{name} exported by the production library"
+    assert not any(n.startswith("cidnet_debug") for n in _lib.parse_header())
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
     from hvi_cidnet_amd.hvi_transform import RGB_HVI

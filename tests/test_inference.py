@@ -60,3 +60,42 @@ def test_enhance_matches_oracle_composition(dev, gamma, alpha_s, alpha_i, gated)
     ref = O.cidnet_forward(p, x, gated=gated, alpha_s=alpha_s, gated2=gated, alpha=alpha_i)
     ref = torch.clamp(ref, 0, 1)[0, :, :37, :51]
     assert (out.cpu() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_no_grad_inference_stores_no_backward_tensors(dev):
+    """Under torch.no_grad() with default (requires_grad=True) parameters, the tensors only the backward reads -- the IEL's
+    u and the PReLU pre-activations of the down / up blocks -- are not allocated: the C ABI receives null pointers
+    (ctx.needs_input_grad stays True for parameters under no_grad, so the modules decide)."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd import _lib
+    m = P.CIDNet(channels=[12, 12, 24, 48]).to(dev)
+    assert all(p.requires_grad for p in m.parameters())
+    L = _lib.lib()
+    seen = {}
+    orig = L.call
+
+    def spy(name, *args):
+        if name in ("cidnet_iel_dw_gate_fwd", "cidnet_down_prelu_fwd", "cidnet_pw_conv_up_prelu", "cidnet_iel_fwd"):
+            seen.setdefault(name, []).append(args)
+        return orig(name, *args)
+    L.call = spy
+    try:
+        x = torch.rand(1, 3, 32, 48, device=dev)
+        with torch.no_grad():
+            m(x)
+        infer = {k: list(v) for k, v in seen.items()}
+        seen.clear()
+        m(x)
+        train = {k: list(v) for k, v in seen.items()}
+    finally:
+        L.call = orig
+
+    def nulls(calls, idx):
+        return [a[idx] is None or getattr(a[idx], "value", 1) is None for a in calls]
+    assert infer.get("cidnet_down_prelu_fwd") and all(nulls(infer["cidnet_down_prelu_fwd"], 2))
+    assert not any(nulls(train["cidnet_down_prelu_fwd"], 2))
+    assert infer.get("cidnet_pw_conv_up_prelu") and all(nulls(infer["cidnet_pw_conv_up_prelu"], 8))
+    assert not any(nulls(train["cidnet_pw_conv_up_prelu"], 8))
+    if "cidnet_iel_dw_gate_fwd" in infer:
+        assert all(nulls(infer["cidnet_iel_dw_gate_fwd"], 4)) and not any(nulls(train["cidnet_iel_dw_gate_fwd"], 4))

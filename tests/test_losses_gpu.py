@@ -92,3 +92,44 @@ def test_cidnet_loss_composition(dev):
     # |.| kinks of the L1 terms and the hue branch cuts of HVIT: compare where the two gradients can agree
     ok = d <= 2e-4 * o64.grad.abs().max().item() + 1e-9
     assert ok.double().mean().item() > 0.995, f"only {ok.double().mean().item():.4f} of the gradient entries agree"
+
+
+def test_cidnet_loss_density_k_gradient_through_target(dev):
+    """train.py:60-65: gt_hvi = model.HVIT(gt_rgb) is not detached, so density_k gets gradient through the output AND
+    the target of every HVI-space term (they largely cancel as the output approaches gt).  The trans.density_k
+    gradient of CIDNetLoss must equal the oracle's with k a differentiable leaf on both sides, and each loss class
+    must hand its target the right gradient."""
+    import hvi_cidnet_amd as P
+    m = P.CIDNet(channels=[12, 12, 24, 48]).to(dev)
+    crit = P.CIDNetLoss(m, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0)
+    out = O.synthetic_batch(141, (2, 3, 32, 48))
+    gt = (0.7 * out + 0.3 * O.synthetic_batch(142, (2, 3, 32, 48))).clamp(0, 1)
+    od = out.to(dev).requires_grad_(True)
+    m.trans.density_k.grad = None
+    loss = crit(od, gt.to(dev))
+    loss.backward()
+    k64 = m.trans.density_k.detach().cpu().double().requires_grad_(True)
+    o64 = out.double().requires_grad_(True)
+    oh, gh = O.hvit(o64, k64), O.hvit(gt.double(), k64)
+    ref = ((o64 - gt.double()).abs().mean() + O.ssim_loss(o64, gt.double(), 0.5) + O.edge_loss(o64, gt.double(), 50.0)) + \
+        1.0 * ((oh - gh).abs().mean() + O.ssim_loss(oh, gh, 0.5) + O.edge_loss(oh, gh, 50.0))
+    ref.backward()
+    gk, rk = m.trans.density_k.grad.item(), k64.grad.item()
+    # the output-only half (what a detached target would give) is far from the full value: the test can tell them apart
+    k2 = m.trans.density_k.detach().cpu().double().requires_grad_(True)
+    oh2, gh2 = O.hvit(out.double(), k2), O.hvit(gt.double(), k2).detach()
+    ((oh2 - gh2).abs().mean() + O.ssim_loss(oh2, gh2, 0.5) + O.edge_loss(oh2, gh2, 50.0)).backward()
+    assert abs(k2.grad.item() - rk) > 20 * (2e-3 * abs(rk) + 1e-6), "fixture cannot distinguish a detached target"
+    assert abs(gk - rk) <= 2e-3 * abs(rk) + 1e-6, (gk, rk, k2.grad.item())
+    # per-class target gradients against autograd on the oracle
+    a, b = O.synthetic_batch(143, (2, 3, 24, 40)), O.synthetic_batch(144, (2, 3, 24, 40))
+    for name, mod, fn in (("l1", P.L1Loss(), lambda x, y: (x - y).abs().mean()),
+                          ("ssim", P.SSIM(weight=0.5), lambda x, y: O.ssim_loss(x, y, 0.5)),
+                          ("edge", P.EdgeLoss(loss_weight=50.0), lambda x, y: O.edge_loss(x, y, 50.0))):
+        xd, yd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        (2.0 * mod(xd, yd)).backward()
+        x64, y64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+        (2.0 * fn(x64, y64)).backward()
+        for got, want, which in ((xd.grad, x64.grad, "input"), (yd.grad, y64.grad, "target")):
+            d = (got.cpu().double() - want).abs().max().item()
+            assert d <= 1e-4 * want.abs().max().item() + 1e-10, f"{name} {which} gradient: {d:.3e}"

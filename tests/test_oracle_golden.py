@@ -154,3 +154,44 @@ def test_lr_schedule_matches_reference_sequence(golden, tag):
     ref = g[tag + "_lr"]
     got = np.array([sch.lr_after(n) for n in range(len(ref))])
     assert np.allclose(got, ref, rtol=1e-12, atol=1e-18), np.abs(got - ref).max()
+
+
+def _fp_close(g, tag, name, grad, rel=2e-5):
+    sums, sample, _ = O.grad_fingerprint(grad, 512)
+    ref = _t(g[f"{tag}_gs.{name}"]).double()
+    assert (sample.double() - ref).abs().max().item() <= rel * ref.abs().max().item() + 1e-9, (tag, name)
+    fp = g[f"{tag}_gfp.{name}"]
+    assert abs(sums[0].item() - fp[0]) <= rel * fp[1] + 1e-9 and abs(sums[2].item() - fp[2]) <= rel * fp[1] + 1e-9, (tag, name)
+
+
+def test_fullsize_oracle_matches_reference_fixture(golden):
+    """the oracle at BASELINE.json's image size (1x3x400x600 forward + backward) and the full-width MSSA / TNSM
+    variants reproduce the reference's outputs and gradient fingerprints of tests/golden/fullsize.npz"""
+    g = golden("fullsize")
+    torch.set_num_threads(8)
+    p = O.params_to(O.make_params(5), requires_grad=True)
+    x = O.synthetic_batch(161, (1, 3, 400, 600)).requires_grad_(True)
+    y = O.cidnet_forward(p, x)
+    assert torch.equal(y.detach()[:, :, ::8, ::8], _t(g["a_out_strided"]))
+    (y - O.synthetic_batch(162, (1, 3, 400, 600))).abs().mean().backward()
+    _close(x.grad[:, :, ::8, ::8], g["a_gx_strided"], rel=1e-5)
+    n = 0
+    for name, v in p.items():
+        if v.grad is not None:
+            _fp_close(g, "a", name, v.grad)
+            n += 1
+    assert n == 191 - 13
+    p = O.params_to(O.make_params(5, variant="mssa"), requires_grad=True)
+    y = O.cidnet_forward(p, _t(g["mssa_x"]), variant="mssa")
+    assert torch.equal(y.detach(), _t(g["mssa_out"]))
+    (y - _t(g["mssa_gt"])).abs().mean().backward()
+    for name, v in p.items():
+        _fp_close(g, "mssa", name, v.grad)
+    p = O.params_to(O.make_params(5, variant="tnsm"), requires_grad=True)
+    y, fz = O.cidnet_tnsm_forward(p, _t(g["tnsm_x"]))
+    assert torch.equal(y.detach(), _t(g["tnsm_out"])) and torch.equal(fz.detach(), _t(g["tnsm_noise"]))
+    ((y - _t(g["tnsm_gt"])).abs().mean() + 0.1 * fz.mean()).backward()
+    dead = set(g["tnsm_dead"].tolist())
+    for name, v in p.items():
+        if name not in dead:
+            _fp_close(g, "tnsm", name, v.grad)
