@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--height", type=int, default=400)
     ap.add_argument("--width", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference-leg", action="store_true", help="skip the 32x3x1024x1024 inference measurement (configs[3])")
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
     ap.add_argument("--op-rows", type=int, default=70, help="rows of the per-shape part of --op-table")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient GEMMs on the branch streams")
@@ -92,9 +93,105 @@ def conv3x3_flops(args):
     return 2.0 * 9 * M * K * H * W * B
 
 
+def relaunch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this parent process (which has not touched the GPU) starts
+    N ranks through torch.distributed.run as a CHILD process, relays its output and exits with its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def roofline_plan(B, H, W, channels=(36, 36, 72, 144), heads=(1, 2, 4, 8)):
+    """Algorithmic work of one training step (forward + backward = 3x the forward) under the fused-kernel
+    plan of SURVEY 2a: each fused kernel reads its inputs once and writes its outputs once.  Returns
+    [(name, flops, bytes)] for the whole batch and step.  FLOPs are the reference's (the dead I_LCA5 included)."""
+    c1, c2, c3, c4 = channels
+    hw = [H * W, H * W // 4, H * W // 16, H * W // 64]
+    k = []
+
+    def add(name, flops, nbytes):
+        k.append((name, 3.0 * B * flops, 3.0 * B * nbytes))
+    add("hvit", 0.0, 24.0 * hw[0])
+    add("stems (1->36, 3->36, replicate)", 2.0 * 9 * (1 + 3) * c1 * hw[0], 4.0 * (1 + 3 + 2 * c1) * hw[0])
+    for lvl, (ci, co) in enumerate(((c1, c2), (c2, c3), (c3, c4))):
+        for br in ("I", "HV"):
+            add(f"down L{lvl} {br} (conv3x3+bilinear+prelu)", 2.0 * 9 * ci * co * hw[lvl], 4.0 * (ci * hw[lvl] + co * hw[lvl + 1]))
+    lcas = [(c2, 1, heads[1])] * 2 + [(c3, 2, heads[2])] * 2 + [(c4, 3, heads[3])] * 4 + [(c3, 2, heads[2])] * 2 + [(c2, 1, heads[1])] * 2
+    for i, (c, lvl, nh) in enumerate(lcas):
+        px = hw[lvl]
+        h = int(c * 2.66)
+        cab = 2.0 * c * 3 * c * px + 2.0 * 9 * 3 * c * px + 2.0 * c * (c // nh) * px * 2 + 2.0 * c * c * px
+        add(f"lca{i} CAB (LN+1x1+dw+gram | attn.v+proj+res)", cab, 4.0 * 5 * c * px)
+        iel = 2.0 * c * 2 * h * px + 2.0 * 9 * 2 * h * px + 2.0 * 9 * 2 * h * px + 2.0 * h * c * px
+        add(f"lca{i} IEL (LN+1x1+dw+gate+1x1)", iel, 4.0 * 2 * c * px)
+    for lvl, (ci, co) in ((3, (c4, c3)), (2, (c3, c2)), (1, (c2, c1))):
+        for br in ("I", "HV"):
+            add(f"up L{lvl} {br} (conv3x3+bilinear+cat+1x1+prelu)", 2.0 * 9 * ci * co * hw[lvl] + 2.0 * 2 * co * co * hw[lvl - 1],
+                4.0 * (ci * hw[lvl] + 2 * co * hw[lvl - 1]))
+    add("heads (36->2, 36->1, replicate)", 2.0 * 9 * c1 * 3 * hw[0], 4.0 * (2 * c1 + 3) * hw[0])
+    add("phvit + residual", 0.0, 36.0 * hw[0])
+    return k
+
+
+def whole_step_roofline(a, ms_per_step):
+    plan = roofline_plan(a.batch, a.height, a.width)
+    floor_s = sum(max(b / (PEAK_HBM_GBS * 1e9), f / (PEAK_F32_MFMA_TFLOPS * 1e12)) for _, f, b in plan)
+    flops, nbytes = sum(f for _, f, _ in plan), sum(b for _, _, b in plan)
+    return {"definition": "sum over the fused-kernel plan (SURVEY 2a/8d) of max(bytes/8 TB/s, flops/157.3 TFLOP/s) / measured step time",
+            "floor_ms": round(1e3 * floor_s, 3), "measured_ms": round(ms_per_step, 3), "frac": round(1e3 * floor_s / ms_per_step, 4),
+            "alg_tflop_per_step": round(flops / 1e12, 4), "alg_gb_per_step": round(nbytes / 1e9, 3),
+            "achieved_tflops": round(flops / 1e12 / (ms_per_step * 1e-3), 2)}
+
+
+def inference_1024(dev):
+    """configs[3]: CIDNet inference on 32x3x1024x1024 (img/s) and the HBM rate of the HVIT / PHVIT kernels on that batch,
+    measured after the timed region (rank 0, one GPU)."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd import ops
+    B, H, W = 32, 1024, 1024
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    x = torch.rand((B, 3, H, W), device=dev, generator=g)
+    k = torch.full([1], 0.2, device=dev)
+
+    def timeit(fn, iters):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    px = B * H * W
+    m = P.CIDNet().to(dev).eval()
+    with torch.no_grad():
+        hvi = ops.HVITFn.apply(x, k)
+        ms_h = timeit(lambda: ops.HVITFn.apply(x, k), 10)
+        ms_p = timeit(lambda: ops.PHVITFn.apply(hvi, None, None, 0.2, False, 1.3, False, 1.0), 10)
+        ms = timeit(lambda: m(x), 3)
+    del m, x, hvi
+    torch.cuda.empty_cache()
+    return {"workload": "CIDNet inference 32x3x1024x1024 fp32 (BASELINE.json configs[3])", "images_per_s": round(B / (ms * 1e-3), 1),
+            "ms_per_batch": round(ms, 2), "hvit_GBs": round(24.0 * px / (ms_h * 1e-3) / 1e9, 1),
+            "phvit_GBs": round(24.0 * px / (ms_p * 1e-3) / 1e9, 1), "hbm_peak_GBs": PEAK_HBM_GBS, "alg_bytes_per_px": 24}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)"
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP library is the only compute path)"
@@ -197,11 +294,15 @@ def main():
                 print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
         roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad, MFMA launches)",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(), "traffic_source": PMC_TRAFFIC_FILE,
                 "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
                 "measured_in": "2 extra single-stream steps after the timed region (HIP events per launch)",
                 "share_of_step_kernel_time": round(c3_ms / tot, 3) if tot else None}
 
+        roof["whole_step"] = whole_step_roofline(a, 1e3 * dt / a.steps)
+        infer = None
+        if world == 1 and not a.no_inference_leg and (a.height, a.width, a.batch) == (400, 600, 8):
+            infer = inference_1024(dev)
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(a)
@@ -213,8 +314,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CIDNet fwd+bwd bs={a.batch}/GPU 3x{a.height}x{a.width} fp32 (BASELINE.json configs[1])",
-                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
+            "roofline": roof, "cpu_baseline": cpu, "inference_1024": infer,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -222,12 +323,15 @@ def main():
         dist.destroy_process_group()
 
 
+PMC_TRAFFIC_FILE = "profiles/r01_pmc_conv3_traffic.json"
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_conv3_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction);
     counters cannot be read from inside this process, so this is null if the summary is absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv3_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
         return int(d["avg_hbm_bytes_per_launch"])
     except Exception:
         return None
