@@ -20,7 +20,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # hvi.hip mirrors the reference's fp32 operation order (bit-exact masks/sextants): no implicit FMA
 # dw.hip: the SLP vectoriser packs the stencil FMAs into v_pk_fma_f32 and pays for it with register-pair shuffles
 # (more instructions in total, and past 256 VGPRs in the gate backward): the kernels there are VALU-issue-bound
-PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] if not os.environ.get("CIDNET_DW_SLP") else []}
+# iel.hip: same for the stencil stages of the tile-resident IEL kernel
+PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] if not os.environ.get("CIDNET_DW_SLP") else [],
+            "iel.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():

@@ -20,12 +20,25 @@ constexpr int kMinRows = 8, kMaxRows = 24;
 constexpr int kSub = 4;     // 256-item groups a fused-backward block walks before reducing
 
 __device__ __forceinline__ f32x4 stencil(const Win6& a, const Win6& b, const Win6& c, const float* w) {
-  f32x4 o;
+  // Tap-major: the four pixels' FMA chains advance together.  Written pixel by pixel, each output compiles to one
+  // 9-deep dependent chain after the other, and a wave then issues at the FMA latency instead of the issue rate (these
+  // kernels are VALU-bound).  Per pixel the operations and their order are unchanged: results are bit-identical.
+  float v[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    o[e] = w[0] * a.v[e] + w[1] * a.v[e + 1] + w[2] * a.v[e + 2] + w[3] * b.v[e] + w[4] * b.v[e + 1] + w[5] * b.v[e + 2] +
-           w[6] * c.v[e] + w[7] * c.v[e + 1] + w[8] * c.v[e + 2];
-  return o;
+  for (int e = 0; e < 4; ++e) v[e] = w[0] * a.v[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaf(w[1], a.v[e + 1], v[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaf(w[2], a.v[e + 2], v[e]);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(w[3 + t], b.v[e + t], v[e]);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(w[6 + t], c.v[e + t], v[e]);
+  return f32x4{v[0], v[1], v[2], v[3]};
 }
 
 struct Item {
@@ -201,12 +214,25 @@ __global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const float* __re
   // u on the columns x0-1 .. x0+4 of row r, from pin rows r-1, r, r+1 (8-wide); zero outside the image
   auto u_row = [&](const Win8& a, const Win8& m, const Win8& z, const float (&w)[9], int r) {
     Win6 o;
+    float v[6];                               // tap-major over the six columns (see stencil())
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = w[0] * a.v[i];
+#pragma unroll
+    for (int t = 1; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = fmaf(w[t], a.v[i + t], v[i]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = fmaf(w[3 + t], m.v[i + t], v[i]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = fmaf(w[6 + t], z.v[i + t], v[i]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const float v = w[0] * a.v[i] + w[1] * a.v[i + 1] + w[2] * a.v[i + 2] + w[3] * m.v[i] + w[4] * m.v[i + 1] + w[5] * m.v[i + 2] +
-                      w[6] * z.v[i] + w[7] * z.v[i + 1] + w[8] * z.v[i + 2];
       const int x = x0 - 1 + i;
-      o.v[i] = (r >= 0 && r < H && x >= 0 && x < W) ? v : 0.f;
+      o.v[i] = (r >= 0 && r < H && x >= 0 && x < W) ? v[i] : 0.f;
     }
     return o;
   };
@@ -362,12 +388,24 @@ struct GateRow {      // da, ds of one row on the 6-wide window x0-1 .. x0+4, fo
 __device__ __forceinline__ GateRow gate_bwd_row(const Win8& a0, const Win8& a1, const Win8& a2, const Win8& b0, const Win8& b1,
                                                 const Win8& b2, const Win6& dg, const float* wa, const float* wb) {
   GateRow o;
+  float c1v[6], c2v[6];                       // tap-major over the twelve chains (see stencil())
+#pragma unroll
+  for (int jx = 0; jx < 6; ++jx) { c1v[jx] = wa[0] * a0.v[jx]; c2v[jx] = wb[0] * b0.v[jx]; }
+#pragma unroll
+  for (int t = 1; t < 3; ++t)
+#pragma unroll
+    for (int jx = 0; jx < 6; ++jx) { c1v[jx] = fmaf(wa[t], a0.v[jx + t], c1v[jx]); c2v[jx] = fmaf(wb[t], b0.v[jx + t], c2v[jx]); }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int jx = 0; jx < 6; ++jx) { c1v[jx] = fmaf(wa[3 + t], a1.v[jx + t], c1v[jx]); c2v[jx] = fmaf(wb[3 + t], b1.v[jx + t], c2v[jx]); }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int jx = 0; jx < 6; ++jx) { c1v[jx] = fmaf(wa[6 + t], a2.v[jx + t], c1v[jx]); c2v[jx] = fmaf(wb[6 + t], b2.v[jx + t], c2v[jx]); }
 #pragma unroll
   for (int jx = 0; jx < 6; ++jx) {
-    const float c1 = wa[0] * a0.v[jx] + wa[1] * a0.v[jx + 1] + wa[2] * a0.v[jx + 2] + wa[3] * a1.v[jx] + wa[4] * a1.v[jx + 1] +
-                     wa[5] * a1.v[jx + 2] + wa[6] * a2.v[jx] + wa[7] * a2.v[jx + 1] + wa[8] * a2.v[jx + 2];
-    const float c2 = wb[0] * b0.v[jx] + wb[1] * b0.v[jx + 1] + wb[2] * b0.v[jx + 2] + wb[3] * b1.v[jx] + wb[4] * b1.v[jx + 1] +
-                     wb[5] * b1.v[jx + 2] + wb[6] * b2.v[jx] + wb[7] * b2.v[jx + 1] + wb[8] * b2.v[jx + 2];
+    const float c1 = c1v[jx], c2 = c2v[jx];
     const float t1 = tanh_fast(c1), t2 = tanh_fast(c2);
     const float s1 = t1 + a1.v[jx + 1], s2 = t2 + b1.v[jx + 1];
     const float g = dg.v[jx];
@@ -448,14 +486,21 @@ __global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* 
       }
       const int q = r - 1;                                     // du row q needs da rows q-1 (gm), q (gc), q+1 (gn)
       if (q >= y0 && q < yend) {
-        f32x4 d1, d2;
+        f32x4 d1, d2;                         // tap-major over the eight chains (see stencil())
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          d1[e] = gc.ds1[e + 1] + fa[0] * gm.da1[e] + fa[1] * gm.da1[e + 1] + fa[2] * gm.da1[e + 2] + fa[3] * gc.da1[e] +
-                  fa[4] * gc.da1[e + 1] + fa[5] * gc.da1[e + 2] + fa[6] * gn.da1[e] + fa[7] * gn.da1[e + 1] + fa[8] * gn.da1[e + 2];
-          d2[e] = gc.ds2[e + 1] + fb[0] * gm.da2[e] + fb[1] * gm.da2[e + 1] + fb[2] * gm.da2[e + 2] + fb[3] * gc.da2[e] +
-                  fb[4] * gc.da2[e + 1] + fb[5] * gc.da2[e + 2] + fb[6] * gn.da2[e] + fb[7] * gn.da2[e + 1] + fb[8] * gn.da2[e + 2];
-        }
+        for (int e = 0; e < 4; ++e) { d1[e] = fmaf(fa[0], gm.da1[e], gc.ds1[e + 1]); d2[e] = fmaf(fb[0], gm.da2[e], gc.ds2[e + 1]); }
+#pragma unroll
+        for (int t = 1; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { d1[e] = fmaf(fa[t], gm.da1[e + t], d1[e]); d2[e] = fmaf(fb[t], gm.da2[e + t], d2[e]); }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { d1[e] = fmaf(fa[3 + t], gc.da1[e + t], d1[e]); d2[e] = fmaf(fb[3 + t], gc.da2[e + t], d2[e]); }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { d1[e] = fmaf(fa[6 + t], gn.da1[e + t], d1[e]); d2[e] = fmaf(fb[6 + t], gn.da2[e + t], d2[e]); }
         store_px4<NARROW>(o1, q, x0, W, d1);
         store_px4<NARROW>(o2, q, x0, W, d2);
       }

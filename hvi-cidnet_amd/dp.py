@@ -130,6 +130,8 @@ class DataParallelTrainer:
         # 3 uses per LCA) must be summed by autograd, not written in place
         counts = ops.stop_grad_probe() if self.use_hip else {}
         multi_ids = {id(p) for p in self.params if counts.get(p.data_ptr(), 0) > 1}
+        # single-use parameters whose gradient a kernel writes in place into the arena, possibly on the weight-gradient stream
+        self._arena_ids = {id(p) for p in self.params if counts.get(p.data_ptr(), 0) == 1}
         self.model.zero_grad(set_to_none=True)
         live = order
         dead = [p for p in self.params if id(p) not in fired]
@@ -171,7 +173,6 @@ class DataParallelTrainer:
         self._pending = [0] * len(self.buckets)
         # 4) gradients written in place by the HIP backward kernels (single-use parameters only)
         multi = [p.data_ptr() for p in live if id(p) in multi_ids]      # pointers AFTER re-homing into flat_p
-        self._multi_ids = multi_ids
         if self.use_hip:
             from . import ops
             ops.set_grad_arena(self.flat_p, self.flat_g, exclude_ptrs=multi)
@@ -191,10 +192,11 @@ class DataParallelTrainer:
         off, n = self._slices[id(p)]
         slot = self.flat_g[off:off + n]
         if p.grad.data_ptr() != slot.data_ptr():
-            # multi-use parameters (summed by autograd on the branch streams) -- or a single-use gradient autograd
-            # cloned instead of stealing: that one may still be in flight on the weight-gradient stream, so the copy
-            # waits for it (never seen in practice; without the wait it would read a stale gradient)
-            if self.use_hip and self.wgrad_stream and p.grad.is_cuda and id(p) not in getattr(self, "_multi_ids", ()):
+            # multi-use parameters and gradients not produced through grad_like() (summed / allocated by autograd on the
+            # branch streams) -- or a single-use arena gradient that autograd cloned instead of stealing: that one may
+            # still be in flight on the weight-gradient stream, so the copy waits for it (never seen in practice;
+            # without the wait it would read a stale gradient)
+            if self.use_hip and self.wgrad_stream and p.grad.is_cuda and id(p) in self._arena_ids:
                 self._join_wgrad_stream()
             slot.copy_(p.grad.reshape(-1))
         p.grad = None                               # the arena is the single home of gradients

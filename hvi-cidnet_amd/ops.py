@@ -5,6 +5,7 @@ provides device memory, the stream and the autograd tape.  Inputs must be fp32 t
 device -- anything else raises (no CPU / ATen fallback exists in this package).
 """
 import ctypes
+import os
 
 import torch
 
@@ -427,6 +428,12 @@ class CABResidualFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # K8: IEL gated FFN:  out = [res +] Wout * gate(dw(Win * xn))
 # --------------------------------------------------------------------------------------------
+# tile-resident IEL kernels (csrc/iel.hip): "fwd" the fused forward, "bwd" the fused backward pair; a training
+# forward only takes the fused path when the fused backward exists (it saves xn and u, not pin / gate)
+# Off by default: at fp32 the fused forward measures 500-570 us against the chain's 460 us at 8x36x200x300 (csrc/iel.hip).
+IEL_FUSED = {"fwd": os.environ.get("CIDNET_IEL_FUSED", "0") == "1", "bwd": False}
+
+
 class IELFn(torch.autograd.Function):
     """Reference: IEL.forward (net/LCA.py:60-67); `res` is the residual of I_LCA (LCA.py:92)."""
 
@@ -439,6 +446,18 @@ class IELFn(torch.autograd.Function):
         HW = H * W
         h = w_dw1.shape[0]
         dev = xn.device
+        ctx.fused = False
+        if IEL_FUSED["fwd"] and (not train or IEL_FUSED["bwd"]) and _raw("cidnet_iel_fwd_supported", C, h):
+            # tile-resident kernel (csrc/iel.hip): the hidden tensors never reach HBM; u is written only for the backward
+            u = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32) if train else None
+            out = torch.empty_like(xn)
+            lib().call("cidnet_iel_fwd", _p(xn), _p(res), _p(w_in), _p(w_dw), _p(w_dw1), _p(w_dw2), _p(w_out), _p(u), _p(out),
+                       B, C, h, H, W, _stream())
+            if train:
+                ctx.fused = True
+                ctx.save_for_backward(xn, u, w_in, w_dw, w_dw1, w_dw2, w_out)
+            ctx.has_res = res is not None
+            return out
         pin = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32)
         pw_conv(xn, 0, C * HW, w_in, 0, 0, C, 1, pin, 0, 2 * h * HW, B, 2 * h, C, HW)
         u = torch.empty_like(pin) if train else None      # inference: u (read only by the backward) is not stored

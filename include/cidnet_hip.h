@@ -111,6 +111,15 @@ void cidnet_debug_dw_rows(int rows);
 #endif
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend,
                  float* out, int flip, int B, int C, int H, int W, void* stream);
+/* ---- K8 fused: tile-resident IEL forward (net/LCA.py:60-67 [+ the residual of I_LCA, LCA.py:92]) -------------
+ * out = [res +] W_out * ((tanh(dw1 u1) + u1) * (tanh(dw2 u2) + u2)),  [u1; u2] = dw(W_in * xn), in ONE kernel: the
+ * hidden tensors live in LDS only (csrc/iel.hip).  xn, res, out: (B,C,H,W); w_in (2h,C), w_dw (2h,1,3,3),
+ * w_dw1 / w_dw2 (h,1,3,3), w_out (C,h).  u (B,2h,H,W) is written when non-NULL (the backward reads it); res may be
+ * NULL.  cidnet_iel_fwd_supported: channel counts the kernel is instantiated for (others: CIDNET_ERR_SHAPE). */
+int cidnet_iel_fwd_supported(int C, int h);
+int cidnet_iel_fwd(const float* xn, const float* res, const float* w_in, const float* w_dw, const float* w_dw1,
+                   const float* w_dw2, const float* w_out, float* u, float* out, int B, int C, int h, int H, int W,
+                   void* stream);
 long cidnet_dw3x3_wgrad_ws_floats(int B, int C, int H, int W);
 int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw2, int csplit,
                        float* ws, long ws_floats, int B, int C, int H, int W, void* stream);

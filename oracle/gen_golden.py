@@ -606,6 +606,15 @@ def gen_fullsize():
     print(f"  ok  400x600 grads: worst rel-to-max diff oracle vs reference {worst:.2e}")
     assert worst < 1e-4
     _store_grads(out, "a", live, FULL_TENSORS)
+    # fp64 truth of the same gradients: at this size the reference's own fp32 gradients sit 4e-4 .. 5e-3 (of each
+    # tensor's max; 0.2 for a nearly-cancelling PReLU slope) from it, so the GPU bar is "no further from fp64 than
+    # twice the reference's own distance", as for TNSM
+    p64 = O.params_to(p, dtype=torch.float64, requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
+    (O.cidnet_forward(p64, x64) - gt.double()).abs().mean().backward()
+    _store_grads(out, "a64", [(n, v.grad.float()) for n, v in p64.items() if v.grad is not None], FULL_TENSORS)
+    out["a64_gx_strided"] = x64.grad[:, :, ::8, ::8].float().numpy()
+    out["a64_gx_fp"] = O.grad_fingerprint(x64.grad)[0].numpy()
     # ---- (b) ----
     p1 = O.make_params(5, jitter=False)
     m = RefCIDNet()

@@ -9,7 +9,9 @@ oracle/gen_golden.py::gen_fullsize through the imported reference):
 
 Large gradient tensors are stored as a fingerprint (sum, sum|.|, dot with a fixed weight vector) plus a strided
 sample (oracle.grad_fingerprint); one tensor per kernel family is stored whole.
-Bars: outputs 1e-4 abs (north star), gradients 2e-4 of the tensor's max (+1e-7)."""
+Bars: outputs 1e-4 abs (north star).  Gradients at 400x600: the reference's own fp32 gradients sit 4e-4 .. 5e-3 of each
+tensor's max away from the fp64 truth (0.2 for a nearly-cancelling PReLU slope; measured, oracle/gen_golden.py), so the
+fixture also holds the fp64 gradients and the bar is: our distance from fp64 <= 2x the reference's own + 2e-4 of the max."""
 import numpy as np
 import pytest
 import torch
@@ -28,24 +30,46 @@ def load(module, params):
     module.load_state_dict({k: params[k] for k in module.state_dict().keys()}, strict=True)
 
 
-def check_grad(g, tag, name, grad, rel=2e-4, sum_rel=2e-4):
-    """gradient tensor `grad` of parameter `name` against the fixture group `tag`"""
+def check_grad(g, tag, name, grad, rel=2e-4, sum_rel=2e-4, tag64=None):
+    """gradient tensor `grad` of parameter `name` against the fixture group `tag` (the reference's fp32 values).
+    With `tag64` (fp64 truth of the same gradient) the bar is relative to the reference's OWN fp32 rounding distance
+    from fp64: ours may be at most twice as far (+ rel of the tensor's max)."""
     sums, sample, _ = O.grad_fingerprint(grad, 512)
     ref_s, ref_fp = _t(g[f"{tag}_gs.{name}"]).double(), g[f"{tag}_gfp.{name}"]
-    scale = ref_s.abs().max().item()
-    d = (sample.double() - ref_s).abs().max().item()
-    assert d <= rel * scale + 1e-7, f"{tag} d{name}: strided sample differs by {d:.3e} (max |g| {scale:.3e})"
-    # sums: fp32 summation noise of n elements ~ sqrt(n) ulp of the typical element
-    tol = sum_rel * ref_fp[1] + 1e-7
-    assert abs(sums[0].item() - ref_fp[0]) <= tol, f"{tag} d{name}: sum {sums[0].item():.6e} vs {ref_fp[0]:.6e}"
-    assert abs(sums[2].item() - ref_fp[2]) <= tol, f"{tag} d{name}: weighted sum {sums[2].item():.6e} vs {ref_fp[2]:.6e}"
     key = f"{tag}_g.{name}"
-    if key in g.files:
-        ref = _t(g[key]).double()
-        d = (grad.detach().cpu().double() - ref).abs().max().item()
-        assert d <= rel * ref.abs().max().item() + 1e-7, f"{tag} d{name}: full tensor differs by {d:.3e}"
-        return 1
-    return 0
+    full = _t(g[key]).double() if key in g.files else None
+    ours_full = grad.detach().cpu().double()
+    if tag64 is None:
+        scale = ref_s.abs().max().item()
+        d = (sample.double() - ref_s).abs().max().item()
+        assert d <= rel * scale + 1e-7, f"{tag} d{name}: strided sample differs by {d:.3e} (max |g| {scale:.3e})"
+        tol = sum_rel * ref_fp[1] + 1e-7
+        assert abs(sums[0].item() - ref_fp[0]) <= tol, f"{tag} d{name}: sum {sums[0].item():.6e} vs {ref_fp[0]:.6e}"
+        assert abs(sums[2].item() - ref_fp[2]) <= tol, f"{tag} d{name}: weighted sum {sums[2].item():.6e} vs {ref_fp[2]:.6e}"
+        if full is not None:
+            d = (ours_full - full).abs().max().item()
+            assert d <= rel * full.abs().max().item() + 1e-7, f"{tag} d{name}: full tensor differs by {d:.3e}"
+        return int(full is not None)
+    s64, fp64 = _t(g[f"{tag64}_gs.{name}"]).double(), g[f"{tag64}_gfp.{name}"]
+    scale = s64.abs().max().item()
+    ref_err = (ref_s - s64).abs().max().item()
+    our_err = (sample.double() - s64).abs().max().item()
+    assert our_err <= 2.0 * ref_err + rel * scale + 1e-10, \
+        f"{tag} d{name}: sample error vs fp64 {our_err:.3e}, reference's own {ref_err:.3e}, max |g| {scale:.3e}"
+    for i in (0, 2):
+        ref_e, our_e = abs(ref_fp[i] - fp64[i]), abs(sums[i].item() - fp64[i])
+        # n elements with independent rounding errors of `rel` of the typical magnitude move the sum by ~ sum|g| / sqrt(n);
+        # correlated fp32 summation-order effects were measured up to 2e-6 of sum|g| (a dropped border tap or tile would
+        # show at >= 1e-3 of it)
+        assert our_e <= 2.0 * ref_e + max(sum_rel / grad.numel() ** 0.5, 1e-5) * fp64[1] + 1e-10, \
+            f"{tag} d{name}: sum[{i}] error vs fp64 {our_e:.3e}, reference's own {ref_e:.3e}, sum|g| {fp64[1]:.3e}"
+    if full is not None:
+        f64 = _t(g[f"{tag64}_g.{name}"]).double()
+        ref_err = (full - f64).abs().max().item()
+        our_err = (ours_full - f64).abs().max().item()
+        assert our_err <= 2.0 * ref_err + rel * f64.abs().max().item() + 1e-10, \
+            f"{tag} d{name}: full-tensor error vs fp64 {our_err:.3e}, reference's own {ref_err:.3e}"
+    return int(full is not None)
 
 
 @pytest.mark.parametrize("batch", [1, 8])
@@ -73,17 +97,19 @@ def test_cidnet_400x600_fwd_bwd_golden(golden, dev, batch):
     loss.backward()
     # d(loss)/d(input): each of the identical samples carries 1/batch of the single-sample gradient
     gx = x.grad[batch - 1:batch].detach().cpu() * batch
-    refx = _t(g["a_gx_strided"])
-    d = (gx[:, :, ::8, ::8] - refx).abs().max().item()
-    assert d <= 2e-4 * refx.abs().max().item() + 1e-9, f"d/dx differs by {d:.3e}"
+    refx, x64 = _t(g["a_gx_strided"]).double(), _t(g["a64_gx_strided"]).double()
+    ref_err = (refx - x64).abs().max().item()
+    our_err = (gx[:, :, ::8, ::8].double() - x64).abs().max().item()
+    assert our_err <= 2.0 * ref_err + 2e-4 * x64.abs().max().item(), f"d/dx error vs fp64 {our_err:.3e}, reference's own {ref_err:.3e}"
     fp = O.grad_fingerprint(gx)[0]
-    assert abs(fp[2].item() - g["a_gx_fp"][2]) <= 2e-4 * g["a_gx_fp"][1]
+    ref_e = abs(g["a_gx_fp"][2] - g["a64_gx_fp"][2])
+    assert abs(fp[2].item() - g["a64_gx_fp"][2]) <= 2.0 * ref_e + 1e-5 * g["a64_gx_fp"][1]
     n_full = n = 0
     for name, prm in m.named_parameters():
         if name.startswith("I_LCA5."):
             assert prm.grad is None
             continue
-        n_full += check_grad(g, "a", name, prm.grad)
+        n_full += check_grad(g, "a", name, prm.grad, tag64="a64")
         n += 1
     assert n == 191 - 13 and n_full >= 16
 

@@ -216,3 +216,40 @@ def test_iel_dw_gate_fwd_fused_equals_unfused(dev, B, h, H, W):
     lib().call("cidnet_iel_dw_gate_fwd", ops._p(pin), ops._p(w), ops._p(w1), ops._p(w2), ops._p(u), ops._p(g), B, h, H, W, ops._stream())
     close(u, u_ref, what="u")
     close(g, g_ref, what="gate")
+
+
+@pytest.mark.parametrize("shape", [(2, 36, 37, 51), (1, 12, 9, 13), (3, 24, 8, 8), (2, 72, 20, 30), (1, 48, 16, 24), (2, 36, 64, 100)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_iel_fused_forward_equals_chain(dev, shape, with_res):
+    """tile-resident IEL forward (csrc/iel.hip: p, u, gate only in LDS) against the unfused chain the model runs
+    (pw_conv -> dw+gate -> pw_conv), which the golden tests pin to the reference: out within 1e-5, u (the tensor the
+    backward reads) within 2e-6; ragged sizes put tiles on every image border and on the first / last row of the tensor"""
+    from hvi_cidnet_amd import ops
+    B, C, H, W = shape
+    h = int(C * 2.66)
+    g = torch.Generator(device=dev).manual_seed(C + H)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    xn, res = rnd(B, C, H, W), (rnd(B, C, H, W) if with_res else None)
+    w_in, w_dw = rnd(2 * h, C, 1, 1) / C ** 0.5, rnd(2 * h, 1, 3, 3) / 3
+    w1, w2, w_out = rnd(h, 1, 3, 3) / 3, rnd(h, 1, 3, 3) / 3, rnd(C, h, 1, 1) / h ** 0.5
+    assert ops._raw("cidnet_iel_fwd_supported", C, h) == 1
+    old = dict(ops.IEL_FUSED)
+    try:
+        ops.IEL_FUSED.update(fwd=False)
+        ref = ops.IELFn.apply(xn, res, w_in, w_dw, w1, w2, w_out, False)
+        u_ref = torch.empty(B, 2 * h, H, W, device=dev)
+        pin = torch.empty_like(u_ref)
+        ops.pw_conv(xn, 0, C * H * W, w_in, 0, 0, C, 1, pin, 0, 2 * h * H * W, B, 2 * h, C, H * W)
+        ops.dw3x3(pin, w_dw, None, 2 * h, u_ref, B, 2 * h, H, W)
+        u = torch.empty_like(u_ref)
+        out = torch.empty_like(xn)
+        ops.lib().call("cidnet_iel_fwd", ops._p(xn), ops._p(res), ops._p(w_in), ops._p(w_dw), ops._p(w1), ops._p(w2), ops._p(w_out),
+                       ops._p(u), ops._p(out), B, C, h, H, W, ops._stream())
+        ops.IEL_FUSED.update(fwd=True)
+        out2 = ops.IELFn.apply(xn, res, w_in, w_dw, w1, w2, w_out, False)       # the op-layer switch, inference form (no u)
+    finally:
+        ops.IEL_FUSED.update(old)
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out, out2)
+    assert (u - u_ref).abs().max().item() <= 2e-6 * max(1.0, u_ref.abs().max().item())
