@@ -107,7 +107,28 @@ class CIDNet(nn.Module, _HubMixin):
                 t.record_stream(main)
         return out_i, out_hv
 
+    # Back-pressure for callers that drive model(x) / backward() themselves (the trainer has its own): the host enqueues a
+    # forward+backward about twice as fast as the GPU runs it, and every queued pass pins several GiB in the caching
+    # allocator (cross-stream frees wait for their events), which ends in hipMalloc storms and multi-second stalls once
+    # the host is far ahead (dp.DataParallelTrainer, tools/stall_probe.py).  At most `max_queued_forwards` passes may be
+    # in flight; 0 disables the wait.
+    max_queued_forwards = 4
+
+    def _backpressure(self, x):
+        if not (x.is_cuda and self.max_queued_forwards > 0) or torch.cuda.is_current_stream_capturing():
+            return
+        q = getattr(self, "_fwd_events", None)
+        if q is None:
+            q = []
+            object.__setattr__(self, "_fwd_events", q)
+        while len(q) >= self.max_queued_forwards:
+            q.pop(0).synchronize()
+        ev = torch.cuda.Event()
+        ev.record()
+        q.append(ev)
+
     def forward(self, x):
+        self._backpressure(x)
         if x.shape[2] % 8 or x.shape[3] % 8:
             raise RuntimeError(f"CIDNet: H and W must be multiples of 8 (got {tuple(x.shape[2:])}); the reference "
                                "fails in NormUpsample's cat for other sizes (net/transformer_utils.py:64)")

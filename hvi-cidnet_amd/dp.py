@@ -71,16 +71,21 @@ class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, n_buckets: int = 4, loss_fn: Optional[Callable] = None,
                  process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = True, use_graph: bool = False,
-                 max_steps_in_flight: int = 3):
+                 max_steps_in_flight: int = 3, max_queued_bytes: int = 96 << 30):
         self.model = model
-        # The host enqueues a step in ~13 ms and the GPU runs it in ~31 ms: left alone, the host is thousands of
-        # launches ahead after ten steps, and the HIP runtime then blocks one launch for 0.5-2.5 s with the GPU idle
-        # (seen in 5 of 8 bench runs, always around the 10th step; a watchdog stack dump showed the autograd thread
-        # inside a kernel launch).  The trainer therefore waits for the step before the previous one before it
-        # enqueues a new one: the queue never holds more than `max_steps_in_flight` steps, the GPU never starves.
-        # Three, not two: the stall needed ~5.5 steps (4000+ launches) in flight, and a queue of two steps (62 ms of work)
-        # is drained by an ordinary 65 ms host hiccup (seen once under torch.distributed.run: 218 instead of 250 img/s).
+        # Back-pressure.  Nothing in a training step synchronises host and device, and the host enqueues a step in ~13 ms
+        # while the GPU needs ~31 ms.  Root cause of the multi-second stalls of round 1 (tools/stall_probe.py,
+        # profiles/r02_stall_probe_*.txt): every tensor the host frees after it was used on a side stream
+        # (record_stream) stays "active" in the caching allocator until the GPU reaches that point, so nothing of a
+        # still-queued step can be reused -- each queued step pins ~6 GiB, and the allocator hipMallocs that much in NEW
+        # segments per step the host is ahead (reserved memory 30 -> 130 GiB over 24 unthrottled steps, 20-40 device
+        # mallocs per step, single hipMalloc calls of 60 ms once the queue is deep; at ~45 steps ahead the 288 GB are
+        # gone and the allocator falls into its synchronise-free-retry path).  Bounding the run-ahead removes the cause;
+        # the bound is in steps AND in bytes the allocator holds for queued work, so a configuration with more launches
+        # or larger activations per step (TNSM, the full objective, bigger batches) is covered as well.
+        # Three steps, not two: a queue of two steps (62 ms of work) is drained by an ordinary 65 ms host hiccup.
         self.max_steps_in_flight = max(1, int(max_steps_in_flight))
+        self.max_queued_bytes = int(max_queued_bytes)
         self._step_events = []
         self.loss_fn = loss_fn or _default_loss
         self.pg = process_group
@@ -290,6 +295,9 @@ class DataParallelTrainer:
         if x.is_cuda:
             while len(self._step_events) >= self.max_steps_in_flight:
                 self._step_events.pop(0).synchronize()
+            # bytes pinned for queued work = "active" (in use or waiting for a stream event) minus what the host still holds
+            while self._step_events and self._queued_bytes(x.device) > self.max_queued_bytes:
+                self._step_events.pop(0).synchronize()
         if self.use_graph and x.is_cuda:
             loss = self._graph_step(x, gt)
         else:
@@ -304,6 +312,11 @@ class DataParallelTrainer:
             ev.record()
             self._step_events.append(ev)
         return loss
+
+    @staticmethod
+    def _queued_bytes(device):
+        st = torch.cuda.memory_stats(device)
+        return st.get("active_bytes.all.current", 0) - st.get("allocated_bytes.all.current", 0)
 
     def forward_backward(self, x, gt):
         """forward + loss + backward only (gradients left in the flat arena); for timing splits."""
