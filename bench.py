@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay forward+backward as one hipGraph (experiment)")
     ap.add_argument("--full-loss", action="store_true",
                     help="train.py's objective without the VGG term (L1 + SSIM + Edge on RGB and HVI) instead of the metric's L1")
+    ap.add_argument("--p-weight", type=float, default=0.0,
+                    help="with --full-loss: weight of the VGG19 perceptual term (train.py's P_weight, 1e-2 there; random VGG weights here)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the I and HV branches on one stream (default: two streams, kernels of the two branches overlap)")
     return ap.parse_args()
@@ -212,7 +214,7 @@ def main():
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream
     trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream),
-                                  use_graph=a.graph, loss_fn=P.CIDNetLoss(model) if a.full_loss else None)
+                                  use_graph=a.graph, loss_fn=P.CIDNetLoss(model, P_weight=a.p_weight).to(dev) if a.full_loss else None)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     shape = (a.batch, 3, a.height, a.width)
@@ -308,7 +310,7 @@ def main():
             cpu = cpu_baseline(a)
 
         out = {
-            "metric": "images/sec fwd+bwd, CIDNet 400x600 bs=8 (step = fwd + " + ("L1+SSIM+Edge loss on RGB and HVI" if a.full_loss else "L1 loss")
+            "metric": "images/sec fwd+bwd, CIDNet 400x600 bs=8 (step = fwd + " + (("L1+SSIM+Edge" + ("+VGG19-perceptual" if a.p_weight > 0 else "") + " loss on RGB and HVI") if a.full_loss else "L1 loss")
                       + " + bwd + grad all-reduce + Adam)",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",

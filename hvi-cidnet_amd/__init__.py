@@ -14,9 +14,9 @@ from .tnsm import HV_TNSM, I_TNSM, TrainableNoiseSuppression
 from .hvi_transform import RGB_HVI
 from .lca import CAB, IEL, HV_LCA, I_LCA
 from .transformer_utils import LayerNorm, NormDownsample, NormUpsample
-from .losses import L1Loss, SSIM, EdgeLoss, CIDNetLoss
+from .losses import L1Loss, SSIM, EdgeLoss, CIDNetLoss, PerceptualLoss, VGGFeatureExtractor
 from .inference import enhance, load_weights, save_pretrained, pad_to_multiple
 from .schedule import WarmupCosineLR
 
-__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "EdgeLoss", "CIDNetLoss", "enhance", "load_weights", "save_pretrained", "pad_to_multiple",
+__all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "EdgeLoss", "CIDNetLoss", "PerceptualLoss", "VGGFeatureExtractor", "enhance", "load_weights", "save_pretrained", "pad_to_multiple",
            "WarmupCosineLR"]

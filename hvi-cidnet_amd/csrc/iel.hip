@@ -105,8 +105,7 @@ __global__ __launch_bounds__(kIelThreads, 2) void iel_fwd_kernel(IelArgs a) {
   const int y0 = ty * TH, x0 = tx * TW;
   const long HW = (long)H * W;
   const int nchunk = (h + kCP - 1) / kCP;
-  const bool gemm = !SPEC || wave < kNGW;       // this wave runs the MFMA stages
-  const bool sten = !SPEC || wave >= kNGW;      // ... the stencil stages
+  const bool gemm = !SPEC || wave < kNGW;       // this wave runs the MFMA stages (the others, if any, the stencil stages)
 
   // ---------------- GEMM-wave state ----------------
   f32x4 acc[T::UPW][4];

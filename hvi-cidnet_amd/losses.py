@@ -1,7 +1,11 @@
-"""Training losses on device ("next" row f1 of SURVEY section 8): drop-ins for the reference's `L1Loss` and `SSIM`
-(loss/losses.py:10-38, 166-190) and `EdgeLoss` (:41-65) with the same constructor arguments.  The VGG19
-PerceptualLoss (:68-161) needs downloaded weights and is not built; `CIDNetLoss` is the reference's training objective
-(train.py:61-65) without that term."""
+"""Training losses on device ("next" rows f1 and f4 of SURVEY section 8): drop-ins for the reference's `L1Loss` and `SSIM`
+(loss/losses.py:10-38, 166-190), `EdgeLoss` (:41-65) and `PerceptualLoss` (:68-161 over loss/vgg_arch.py:133-239) with
+the same constructor arguments.  `CIDNetLoss` is the reference's training objective (train.py:61-65).  The pretrained
+VGG19 weights cannot be fetched here (torchvision / network absent): `VGGFeatureExtractor` starts from build-owned
+deterministic random weights and loads a torchvision `vgg19` state_dict when one is supplied."""
+from collections import OrderedDict
+
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -50,21 +54,123 @@ class EdgeLoss(nn.Module):
         return ops.EdgeLossFn.apply(x, y, float(self.weight))
 
 
-class CIDNetLoss(nn.Module):
-    """loss_rgb + HVI_weight * loss_hvi with loss_* = L1 + SSIM + Edge (train.py:61-65 without the perceptual term);
-    defaults are data/options.py:56-59.  `model` supplies HVIT for the HVI-space terms, exactly as train.py calls
-    `model.HVIT` on the output and on the ground truth."""
+class VGGFeatureExtractor(nn.Module):
+    """Parameter container with the reference's layout (loss/vgg_arch.py:133-239): `vgg_net.<convN_M>.weight / .bias`
+    for the VGG19 prefix that reaches the deepest requested layer, buffers `mean` / `std`, everything frozen.
+    torchvision's pretrained weights are not available offline; `load_torchvision_state_dict` takes a `vgg19().state_dict()`
+    (keys `features.<i>.weight`) when the user has one."""
 
-    def __init__(self, model, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0):
+    def __init__(self, layer_name_list, vgg_type="vgg19", use_input_norm=True, range_norm=False, requires_grad=False,
+                 remove_pooling=False, pooling_stride=2, seed=19):
+        super().__init__()
+        if vgg_type != "vgg19" or requires_grad or remove_pooling or pooling_stride != 2:
+            raise NotImplementedError("hvi-cidnet_amd builds the extractor as train.py:192 constructs it: frozen vgg19, MaxPool2d(2, 2)")
+        self.layer_name_list = list(layer_name_list)
+        self.use_input_norm = use_input_norm
+        self.range_norm = range_norm
+        self.plan = ops.vgg_plan(self.layer_name_list)
+        gen = torch.Generator().manual_seed(seed)          # identical on every rank, independent of the global RNG
+        mods = OrderedDict()
+        n_pool = 0
+        for layer in self.plan:
+            if layer == "pool":
+                n_pool += 1
+                mods[f"pool{n_pool}"] = nn.MaxPool2d(kernel_size=2, stride=2)
+                continue
+            name, ci, co = layer
+            conv = nn.Conv2d(ci, co, kernel_size=3, padding=1)
+            with torch.no_grad():                           # He-uniform, the scale real VGG activations live at
+                bound = (6.0 / (9 * ci)) ** 0.5
+                conv.weight.copy_((torch.rand(conv.weight.shape, generator=gen) * 2 - 1) * bound)
+                conv.bias.copy_((torch.rand(co, generator=gen) * 2 - 1) * 0.05)
+            mods[name] = conv
+            mods[name.replace("conv", "relu")] = nn.ReLU(inplace=True)
+        last = self.plan[-1][0].replace("conv", "relu")     # the reference cuts the stack at the deepest requested layer
+        mods.pop(last)
+        self.vgg_net = nn.Sequential(mods)
+        for p in self.parameters():
+            p.requires_grad = False
+        if use_input_norm:
+            self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+            self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def conv_params(self):
+        out = []
+        for layer in self.plan:
+            if layer != "pool":
+                conv = getattr(self.vgg_net, layer[0])
+                out += [conv.weight, conv.bias]
+        return out
+
+    def load_torchvision_state_dict(self, sd):
+        """sd: torchvision.models.vgg19().state_dict() (or its `features.` part)"""
+        idx, mapped = 0, {}
+        for layer in ops.VGG19_LAYERS:
+            if layer == "pool":
+                idx += 1
+                continue
+            mapped[layer[0]] = idx
+            idx += 2                                        # conv, relu
+        with torch.no_grad():
+            for layer in self.plan:
+                if layer == "pool":
+                    continue
+                conv = getattr(self.vgg_net, layer[0])
+                i = mapped[layer[0]]
+                conv.weight.copy_(sd.get(f"features.{i}.weight", sd.get(f"{i}.weight")))
+                conv.bias.copy_(sd.get(f"features.{i}.bias", sd.get(f"{i}.bias")))
+
+
+class PerceptualLoss(nn.Module):
+    """Reference: PerceptualLoss, loss/losses.py:68-161, as train.py:192 builds it: layer_weights over 'convN_M' features
+    (before the ReLU), criterion 'mse', no style term.  forward returns (percep_loss, None) like the reference."""
+
+    def __init__(self, layer_weights, vgg_type="vgg19", use_input_norm=True, range_norm=True, perceptual_weight=1.0,
+                 style_weight=0., criterion="l1"):
+        super().__init__()
+        if style_weight > 0:
+            raise NotImplementedError("the style (Gram) term is never enabled by the reference's training loop (style_weight=0)")
+        if criterion != "mse":
+            raise NotImplementedError("hvi-cidnet_amd builds the criterion train.py:192 uses: 'mse'")
+        self.perceptual_weight = perceptual_weight
+        self.style_weight = style_weight
+        self.layer_weights = dict(layer_weights)
+        self.criterion_type = criterion
+        self.vgg = VGGFeatureExtractor(list(layer_weights.keys()), vgg_type=vgg_type, use_input_norm=use_input_norm,
+                                       range_norm=range_norm)
+
+    def forward(self, x, gt):
+        if not self.perceptual_weight > 0:
+            return None, None
+        names = list(self.layer_weights.keys())
+        loss = ops.PerceptualLossFn.apply(x, gt.detach(), names, [float(self.layer_weights[k]) for k in names],
+                                          float(self.perceptual_weight), self.vgg.range_norm, self.vgg.use_input_norm,
+                                          *self.vgg.conv_params())
+        return loss, None
+
+
+class CIDNetLoss(nn.Module):
+    """loss_rgb + HVI_weight * loss_hvi with loss_* = L1 + SSIM + Edge + P_weight * Perceptual (train.py:61-65);
+    defaults are data/options.py:56-59 (P_weight 1e-2 there; 0 here leaves the VGG term out, the round-1 objective).
+    `model` supplies HVIT for the HVI-space terms, exactly as train.py calls `model.HVIT` on the output and on the ground
+    truth.  The perceptual term is built as train.py:192 does: conv1_2 / conv2_2 / conv3_4 / conv4_4, 'mse'."""
+
+    def __init__(self, model, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0, P_weight=0.0):
         super().__init__()
         self.l1 = L1Loss(loss_weight=L1_weight)
         self.ssim = SSIM(weight=D_weight)
         self.edge = EdgeLoss(loss_weight=E_weight)
         self.hvi_weight = HVI_weight
+        self.p_weight = P_weight
+        self.perceptual = PerceptualLoss({"conv1_2": 1, "conv2_2": 1, "conv3_4": 1, "conv4_4": 1}, perceptual_weight=1.0,
+                                         criterion="mse") if P_weight > 0 else None
         self._hvit = model.HVIT
 
     def _terms(self, a, b):
-        return self.l1(a, b) + self.ssim(a, b) + self.edge(a, b)
+        t = self.l1(a, b) + self.ssim(a, b) + self.edge(a, b)
+        if self.perceptual is not None:
+            t = t + self.p_weight * self.perceptual(a, b)[0]
+        return t
 
     def forward(self, output_rgb, gt_rgb):
         loss_hvi = self._terms(self._hvit(output_rgb), self._hvit(gt_rgb))

@@ -822,6 +822,124 @@ class EdgeLossFn(torch.autograd.Function):
         return (gx if ctx.needs_input_grad[0] else None), gy, None
 
 
+# VGG19 feature stack up to conv4_4 (loss/vgg_arch.py:105-110: names; torchvision cfg 'E'): (name, Cin, Cout) or "pool"
+VGG19_LAYERS = (("conv1_1", 3, 64), ("conv1_2", 64, 64), "pool", ("conv2_1", 64, 128), ("conv2_2", 128, 128), "pool",
+                ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), ("conv3_4", 256, 256), "pool",
+                ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512), ("conv4_4", 512, 512), "pool",
+                ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512), ("conv5_4", 512, 512))
+
+
+def vgg_plan(layer_names):
+    """the prefix of VGG19_LAYERS that reaches the deepest requested 'convN_M' feature"""
+    names = [l[0] if l != "pool" else "pool" for l in VGG19_LAYERS]
+    last = max(names.index(n) for n in layer_names)
+    return VGG19_LAYERS[:last + 1]
+
+
+class PerceptualLossFn(torch.autograd.Function):
+    """perceptual_weight * sum_k layer_weight[k] * mse(vgg_k(x), vgg_k(gt)) with the features taken at the conv outputs
+    BEFORE the ReLU: reference PerceptualLoss.forward (loss/losses.py:126-142, criterion 'mse', style_weight 0) over
+    VGGFeatureExtractor.forward (loss/vgg_arch.py:217-239).  gt is detached there (:134) and the VGG weights are frozen,
+    so the only gradient is d/dx.  params = (w, b) per conv layer of the plan, in order."""
+
+    @staticmethod
+    def forward(ctx, x, gt, layer_names, layer_weights, perceptual_weight, range_norm, use_input_norm, *params):
+        _check(x, gt, *params)
+        x, gt = _c(x), _c(gt)
+        B, C, H, W = x.shape
+        if C != 3 or gt.shape != x.shape:
+            raise RuntimeError("PerceptualLoss expects two (B,3,H,W) images of the same shape")
+        plan = vgg_plan(layer_names)
+        dev = x.device
+        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        nws = _raw("cidnet_mse_ws_floats")
+
+        def run(img, feats_gt):
+            """-> (features or None, saved); with feats_gt given, the loss and the feature gradients are formed on the way"""
+            t = torch.empty_like(img)
+            if use_input_norm:
+                lib().call("cidnet_vgg_normalize", _p(img), _p(t), int(bool(range_norm)), B, H * W, _stream())
+            elif range_norm:
+                raise NotImplementedError("range_norm without use_input_norm is not used by the reference's training loop")
+            else:
+                t = img
+            h, w, pi = H, W, 0
+            feats, saved, first = {}, [], True
+            for li, layer in enumerate(plan):
+                if layer == "pool":
+                    y = torch.empty((B, t.shape[1], h // 2, w // 2), device=dev, dtype=torch.float32)
+                    lib().call("cidnet_maxpool2_fwd", _p(t), _p(y), B * t.shape[1], h, w, _stream())
+                    saved.append(("pool", t, h, w))
+                    t, h, w = y, h // 2, w // 2
+                    continue
+                name, ci, co = layer
+                wt, bs = params[2 * pi], params[2 * pi + 1]
+                pi += 1
+                y = torch.empty((B, co, h, w), device=dev, dtype=torch.float32)
+                conv3x3(t, wt, y, B, co, ci, h, w, 9 * ci, 9)
+                is_feat, is_last = name in layer_names, li == len(plan) - 1
+                if is_feat:
+                    act = None if is_last else torch.empty_like(y)
+                    lib().call("cidnet_bias_relu", _p(y), _p(bs), _p(act), B, co, h * w, _stream())
+                    if feats_gt is None:
+                        feats[name] = y
+                        gf = None
+                    else:
+                        gf = torch.empty_like(y)
+                        ws = _ws(nws, dev)
+                        wk = float(perceptual_weight) * float(layer_weights[layer_names.index(name)])
+                        lib().call("cidnet_mse_loss", _p(y), _p(feats_gt[name]), _p(gf), _p(loss), _f(wk), 0 if first else 1, _p(ws),
+                                   ws.numel(), y.numel(), _stream())
+                        first = False
+                    saved.append(("conv", wt, ci, co, h, w, gf, act))
+                    t = act
+                else:
+                    lib().call("cidnet_bias_relu", _p(y), _p(bs), _p(y), B, co, h * w, _stream())
+                    saved.append(("conv", wt, ci, co, h, w, None, y))
+                    t = y
+            return feats, saved
+
+        feats_gt, _ = run(gt, None)
+        need = ctx.needs_input_grad[0]
+        _, saved = run(x, feats_gt)
+        del feats_gt
+        ctx.saved = saved if need else None
+        ctx.meta = (B, H, W, bool(range_norm), bool(use_input_norm))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, range_norm, use_input_norm = ctx.meta
+        saved = ctx.saved
+        d = None                               # gradient wrt the OUTPUT (post-ReLU / pooled) of the layer being walked
+        for idx in range(len(saved) - 1, -1, -1):
+            rec = saved[idx]
+            if rec[0] == "pool":
+                _, tin, h, w = rec
+                gx = torch.empty_like(tin)
+                lib().call("cidnet_maxpool2_bwd", _p(tin), _p(d), _p(gx), tin.shape[0] * tin.shape[1], h, w, _stream())
+                d = gx
+                continue
+            _, wt, ci, co, h, w, gf, act = rec
+            # gradient wrt the pre-activation (conv output + bias): through the ReLU, plus the feature term
+            if d is not None:
+                dp = torch.empty_like(d)
+                lib().call("cidnet_relu_bwd", _p(d), _p(act), _p(dp), d.numel(), _stream())
+                if gf is not None:
+                    lib().call("cidnet_add", _p(dp), _p(gf), _p(dp), dp.numel(), _stream())
+            else:
+                dp = gf                          # deepest layer: only its feature term
+            dx = torch.empty((B, ci, h, w), device=dp.device, dtype=torch.float32)
+            conv3x3(dp, wt, dx, B, ci, co, h, w, 9, 9 * ci, flip=True)
+            d = dx
+        if use_input_norm:
+            gx = torch.empty_like(d)
+            lib().call("cidnet_vgg_normalize_bwd", _p(d), _p(gx), int(range_norm), B, H * W, _stream())
+            d = gx
+        ctx.saved = None
+        return (_scaled(d, g, 1.0), None, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _check(p, g, m, v)
     lib().call("cidnet_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _f(lr), _f(beta1), _f(beta2), _f(eps),

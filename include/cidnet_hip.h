@@ -229,6 +229,23 @@ int cidnet_edge_fwd(const float* x, const float* y, float weight, float* loss, f
                     long ws_floats, int B, int C, int H, int W, void* stream);
 int cidnet_edge_bwd(const float* lap, const float* gloss, float weight, float* gx, float* ws, long ws_floats,
                     int B, int C, int H, int W, void* stream);
+/* ---- "next" row f4: VGG19 perceptual loss pieces (loss/vgg_arch.py:217-239, loss/losses.py:126-142; the 3x3
+ * convolutions are cidnet_conv3x3).  The VGG weights are frozen (requires_grad=False, vgg_arch.py:203-206): data
+ * gradients only.
+ * normalize: y = ((range_norm ? (x + 1) / 2 : x) - mean[c]) / std[c], x (B,3,HW), ImageNet mean / std (:211-214).
+ * bias_relu: x += bias[c] in place (the 'convN_M' feature, taken BEFORE the ReLU), act = max(x, 0) (act may be NULL,
+ *   or x itself for an in-place ReLU).  relu_bwd: gx = act > 0 ? g : 0.
+ * maxpool2: nn.MaxPool2d(2, 2) (:196), output floor(H/2) x floor(W/2); bwd routes to the first maximum in scan order.
+ * mse_loss: loss (+)= weight * mean((a - b)^2), grad = weight * 2 (a - b) / n (criterion 'mse', train.py:192). */
+int cidnet_vgg_normalize(const float* x, float* y, int range_norm, int B, long HW, void* stream);
+int cidnet_vgg_normalize_bwd(const float* g, float* gx, int range_norm, int B, long HW, void* stream);
+int cidnet_bias_relu(float* x, const float* bias, float* act, int B, int C, long HW, void* stream);
+int cidnet_relu_bwd(const float* g, const float* act, float* gx, long n, void* stream);
+int cidnet_maxpool2_fwd(const float* x, float* y, long planes, int H, int W, void* stream);
+int cidnet_maxpool2_bwd(const float* x, const float* gy, float* gx, long planes, int H, int W, void* stream);
+long cidnet_mse_ws_floats(void);
+int cidnet_mse_loss(const float* a, const float* b, float* grad, float* loss, float weight, int accumulate, float* ws,
+                    long ws_floats, long n, void* stream);
 /* torch.optim.Adam step (train.py:166) over one flat buffer; g is multiplied by grad_scale first
  * (1/world_size after a sum all-reduce).  step = 1-based update count. */
 int cidnet_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,

@@ -622,6 +622,48 @@ def synthetic_batch(seed: int, shape, quantised: bool = False) -> torch.Tensor:
     return torch.from_numpy(a)
 
 
+VGG19_NAMES = ("conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "conv3_4", "pool",
+               "conv4_1", "conv4_2", "conv4_3", "conv4_4", "pool", "conv5_1", "conv5_2", "conv5_3", "conv5_4")
+
+
+def vgg_features(x: torch.Tensor, convs: Dict[str, Tuple[torch.Tensor, torch.Tensor]], layer_names, range_norm: bool = True,
+                 use_input_norm: bool = True) -> Dict[str, torch.Tensor]:
+    """Restates VGGFeatureExtractor.forward (loss/vgg_arch.py:217-239): (x + 1) / 2 if range_norm, ImageNet mean / std,
+    then conv(+bias) / ReLU / MaxPool2d(2, 2) in VGG19 order; the feature named 'convN_M' is the conv output BEFORE its
+    ReLU.  PARITY UNPINNED: loss.vgg_arch imports torchvision (absent here) and fetches pretrained weights, so this
+    is restated from the text; `convs` = {name: (weight, bias)}."""
+    if range_norm:
+        x = (x + 1) / 2
+    if use_input_norm:
+        mean = torch.tensor([0.485, 0.456, 0.406], dtype=x.dtype).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], dtype=x.dtype).view(1, 3, 1, 1)
+        x = (x - mean) / std
+    last = max(VGG19_NAMES.index(n) for n in layer_names)
+    out = {}
+    for i, name in enumerate(VGG19_NAMES[:last + 1]):
+        if name == "pool":
+            x = F.max_pool2d(x, kernel_size=2, stride=2)
+            continue
+        w, b = convs[name]
+        x = F.conv2d(x, w.to(x.dtype), b.to(x.dtype), padding=1)
+        if name in layer_names:
+            out[name] = x
+        if i < last:
+            x = F.relu(x)
+    return out
+
+
+def perceptual_loss(x, gt, convs, layer_weights: Dict[str, float], perceptual_weight: float = 1.0, range_norm: bool = True):
+    """PerceptualLoss.forward with criterion 'mse' and no style term (loss/losses.py:126-142, train.py:192)."""
+    names = list(layer_weights.keys())
+    fx = vgg_features(x, convs, names, range_norm)
+    fg = vgg_features(gt.detach(), convs, names, range_norm)
+    loss = 0
+    for k in names:
+        loss = loss + F.mse_loss(fx[k], fg[k]) * layer_weights[k]
+    return loss * perceptual_weight
+
+
 def grad_fingerprint(t: torch.Tensor, max_sample: int = 2048):
     """Compact fixture form of a large tensor: (sums, sample).  sums = [sum, sum|.|, dot with a fixed
     non-periodic weight vector] in fp64 (the dot catches permuted / shifted elements that the plain sums

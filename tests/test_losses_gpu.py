@@ -133,3 +133,47 @@ def test_cidnet_loss_density_k_gradient_through_target(dev):
         for got, want, which in ((xd.grad, x64.grad, "input"), (yd.grad, y64.grad, "target")):
             d = (got.cpu().double() - want).abs().max().item()
             assert d <= 1e-4 * want.abs().max().item() + 1e-10, f"{name} {which} gradient: {d:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 32, 48), (1, 3, 37, 51), (1, 3, 18, 22)])
+def test_perceptual_loss_vs_oracle(dev, shape):
+    """VGG19 perceptual loss ("next" row f4) as train.py:192 builds it (conv1_2, conv2_2, conv3_4, conv4_4 before the ReLU,
+    'mse', range_norm) against the fp64 oracle restated from loss/vgg_arch.py + loss/losses.py (parity unpinned: torchvision
+    is absent): value, d/dx, the frozen weights get no gradient; odd sizes exercise MaxPool2d's floor and its uncovered
+    last row / column in the backward"""
+    import hvi_cidnet_amd as P
+    crit = P.PerceptualLoss({"conv1_2": 1, "conv2_2": 1, "conv3_4": 0.5, "conv4_4": 2}, perceptual_weight=1.5, criterion="mse").to(dev)
+    assert all(not p.requires_grad for p in crit.parameters())
+    keys = list(crit.state_dict().keys())
+    assert "vgg.vgg_net.conv1_1.weight" in keys and "vgg.vgg_net.conv4_4.bias" in keys and "vgg.mean" in keys
+    x = O.synthetic_batch(151, shape) * 2 - 1
+    gt = (0.6 * x + 0.4 * (O.synthetic_batch(152, shape) * 2 - 1))
+    xd = x.to(dev).requires_grad_(True)
+    loss, style = crit(xd, gt.to(dev))
+    assert style is None
+    (0.7 * loss).backward()
+    convs = {n: (getattr(crit.vgg.vgg_net, n).weight.detach().cpu().double(), getattr(crit.vgg.vgg_net, n).bias.detach().cpu().double())
+             for n in O.VGG19_NAMES if n != "pool" and hasattr(crit.vgg.vgg_net, n)}
+    x64 = x.double().requires_grad_(True)
+    ref = O.perceptual_loss(x64, gt.double(), convs, {"conv1_2": 1, "conv2_2": 1, "conv3_4": 0.5, "conv4_4": 2}, 1.5, True)
+    (0.7 * ref).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-9, (loss.item(), ref.item())
+    d = (xd.grad.cpu().double() - x64.grad).abs().max().item()
+    assert d <= 2e-4 * x64.grad.abs().max().item() + 1e-12, (d, x64.grad.abs().max().item())
+
+
+def test_cidnet_loss_with_perceptual_term(dev):
+    """CIDNetLoss(P_weight > 0) = the reference's full objective (train.py:61-65): the VGG term is added on the RGB pair
+    and on the HVIT pair, and the model still trains"""
+    import hvi_cidnet_amd as P
+    m = P.CIDNet(channels=[12, 12, 24, 48]).to(dev)
+    full = P.CIDNetLoss(m, P_weight=1e-2).to(dev)
+    base = P.CIDNetLoss(m, P_weight=0.0)
+    out = O.synthetic_batch(161, (1, 3, 32, 48)).to(dev).requires_grad_(True)
+    gt = O.synthetic_batch(162, (1, 3, 32, 48)).to(dev)
+    lf, lb = full(out, gt), base(out, gt)
+    p_rgb = full.perceptual(out, gt)[0]
+    p_hvi = full.perceptual(m.HVIT(out), m.HVIT(gt))[0]
+    assert abs(lf.item() - (lb.item() + 1e-2 * (p_rgb.item() + p_hvi.item()))) <= 1e-5 * abs(lf.item())
+    lf.backward()
+    assert torch.isfinite(out.grad).all() and out.grad.abs().max().item() > 0
