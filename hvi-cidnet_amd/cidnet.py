@@ -82,6 +82,19 @@ class CIDNet(nn.Module, _HubMixin):
         # dead block is not executed here.
         return i_dec3
 
+    # A down block whose input also feeds a skip connection (net/CIDNet.py:80-81,85-86): with `fold_skip_grads` the skip's
+    # gradient is added in the epilogue of the block's data-gradient conv (ops.DownResFn) instead of by a separate autograd
+    # accumulation pass over the tensor (four per step: two at 400x600, two at 200x300).  Round 1 switched this off after
+    # multi-second host stalls; their cause was the unbounded run-ahead of the host (dp.DataParallelTrainer), not this.
+    fold_skip_grads = True
+
+    def _down_skip(self, block, t):
+        """-> (tensor for the skip connection, block(t))"""
+        if self.fold_skip_grads and torch.is_grad_enabled() and t.requires_grad:
+            y, t_skip = block.forward_res(t)
+            return t_skip, y
+        return t, block(t)
+
     # ---- two-stream execution: the I branch and the HV branch of every stage are independent ----
     two_streams = True
 
@@ -136,15 +149,14 @@ class CIDNet(nn.Module, _HubMixin):
         i = hvi[:, 2:3, :, :].contiguous()
         # low
         (i_enc0, i_enc1), (hv_0, hv_1) = self._par(
-            lambda: (lambda e0: (e0, self.IE_block1(e0)))(self.IE_block0(i)),
-            lambda: (lambda h0: (h0, self.HVE_block1(h0)))(self.HVE_block0(hvi)), (hvi, i))
+            lambda: self._down_skip(self.IE_block1, self.IE_block0(i)),
+            lambda: self._down_skip(self.HVE_block1, self.HVE_block0(hvi)), (hvi, i))
         i_jump0 = i_enc0
         hv_jump0 = hv_0
 
         i_enc2, hv_2 = self._par(lambda: self.I_LCA1(i_enc1, hv_1), lambda: self.HV_LCA1(hv_1, i_enc1), (i_enc1, hv_1))
-        v_jump1 = i_enc2
-        hv_jump1 = hv_2
-        i_enc2, hv_2 = self._par(lambda: self.IE_block2(v_jump1), lambda: self.HVE_block2(hv_jump1), (v_jump1, hv_jump1))
+        (v_jump1, i_enc2), (hv_jump1, hv_2) = self._par(lambda: self._down_skip(self.IE_block2, i_enc2),
+                                                        lambda: self._down_skip(self.HVE_block2, hv_2), (i_enc2, hv_2))
 
         # reference quirk: level-3 encoders take the PRE-LCA2 tensors (net/CIDNet.py:94-95)
         (v_jump2, i_enc3), (hv_jump2, hv_3) = self._par(

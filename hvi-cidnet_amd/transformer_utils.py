@@ -57,9 +57,8 @@ class NormDownsample(nn.Module):
 
     def forward_res(self, x):
         """-> (self(x), x).  For an input that also feeds a skip connection: hand the second result to the skip's
-        consumer and its gradient is folded into this block's data-gradient kernel (ops.DownResFn).  CIDNet.forward
-        does NOT use it: measured +0.3 % on the step, and with the two-stream schedule it provoked multi-second host
-        stalls inside single steps in 4 of 9 bench runs (rejected experiments)."""
+        consumer and its gradient is folded into this block's data-gradient kernel (ops.DownResFn).  CIDNet.forward uses
+        it for the four skip connections that leave a down block's input (cidnet.CIDNet._down_skip)."""
         y, x = ops.DownResFn.apply(x, self.down[0].weight, self.prelu.weight)
         return (self.norm(y) if self.use_norm else y), x
 
