@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--height", type=int, default=400)
     ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the IEL chain's hidden tensors (arithmetic is fp32 either way); f32 is the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference-leg", action="store_true", help="skip the 32x3x1024x1024 inference measurement (configs[3])")
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
@@ -87,6 +89,24 @@ class OpTimer:
             a[0] += 1
             a[1] += e0.elapsed_time(e1)
         return agg
+
+
+def iel_stream_bytes(name, args):
+    """algorithmic HBM bytes of one launch of the IEL chain's streaming kernels (every operand once), from the call's
+    own arguments: element size follows the storage-type code `dt`"""
+    ints = [v for v in args if isinstance(v, int) and not isinstance(v, bool)]
+    if name == "cidnet_iel_dw_gate_fwd_t":          # (pin, wdw, w1, w2, u, g, dt, B, h, H, W): read 2h, write 2h (u) + h
+        dt, B, h, H, W = ints[-5:]
+        return (2 + (2 if args[4] is not None and getattr(args[4], "value", 1) else 0) + 1) * h * B * H * W * (2 if dt else 4)
+    if name == "cidnet_iel_gate_dw_bwd_t":          # (u, w1, w2, dg, du, dt, gw1, gw2, ws, ws_floats, B, h, H, W): read 2h + h, write 2h
+        dt = ints[0]
+        B, h, H, W = ints[-4:]
+        return 5 * h * B * H * W * (2 if dt else 4)
+    if name == "cidnet_dw3x3_bwd_t":                # (in, gout, w1, w2, csplit, addend, gin, dt, ..., B, C, H, W): read 2C, write C
+        dt = ints[1]
+        B, C, H, W = ints[-4:]
+        return 3 * C * B * H * W * (2 if dt else 4)
+    return 0
 
 
 def conv3x3_flops(args):
@@ -210,6 +230,7 @@ def main():
 
     import hvi_cidnet_amd as P
     from hvi_cidnet_amd.dp import DataParallelTrainer
+    P.set_storage_dtype(a.dtype)
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream
@@ -283,8 +304,11 @@ def main():
         timer.remove()
         tot = sum(v[1] for v in agg.values())
         # the MFMA kernel only: the <= 4-channel stem / head launches of cidnet_conv3x3 run on streaming VALU kernels
+        # cidnet_conv3x3_add(X, x_bs, Wt, w_ms, w_ks, flip, replicate, R, r_bs, Y, y_bs, B, M, K, H, W): same kernel with an addend
         c3 = [(args, e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
               if name == "cidnet_conv3x3" and min(args[10], args[11]) > 4]
+        c3 += [(args[:7] + args[9:], e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
+               if name == "cidnet_conv3x3_add" and min(args[12], args[13]) > 4]
         c3_flops = sum(conv3x3_flops(ar) for ar, _ in c3)
         c3_ms = sum(ms for _, ms in c3)
         achieved = c3_flops / (c3_ms * 1e-3) / 1e12 if c3_ms > 0 else 0.0
@@ -294,13 +318,22 @@ def main():
             print(f"  sum of kernel families: {tot / 2:.3f} ms/step; wall {1e3 * dt / a.steps:.3f} ms/step", file=sys.stderr)
             for k, v in sorted(timer.table(by_shape=True).items(), key=lambda kv: -kv[1][1])[:a.op_rows]:
                 print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
-        roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3: dense 3x3 fwd + dgrad, MFMA launches)",
+        roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3 / _add: dense 3x3 fwd + dgrad, MFMA launches)",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(), "traffic_source": PMC_TRAFFIC_FILE,
                 "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
                 "measured_in": "2 extra single-stream steps after the timed region (HIP events per launch)",
                 "share_of_step_kernel_time": round(c3_ms / tot, 3) if tot else None}
 
+        # the HBM-bound side: the streaming kernels of the IEL chain (the tensors the bf16 storage mode halves)
+        hb = [(iel_stream_bytes(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
+              if name in ("cidnet_iel_dw_gate_fwd_t", "cidnet_iel_gate_dw_bwd_t", "cidnet_dw3x3_bwd_t")]
+        hb_bytes, hb_ms = sum(b for b, _ in hb), sum(t for _, t in hb)
+        roof_hbm = {"bound": "hbm", "kernel": "IEL-chain streaming kernels (iel_dw_gate_kernel, iel_gate_dw_bwd_kernel, dw3x3_bwd_kernel)",
+                    "achieved": round(hb_bytes / (hb_ms * 1e-3) / 1e9, 1) if hb_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(hb_bytes / (hb_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if hb_ms > 0 else 0.0,
+                    "traffic": None, "launches_per_step": len(hb) // 2, "alg_gb_per_step": round(hb_bytes / 2 / 1e9, 3),
+                    "ms_per_step": round(hb_ms / 2, 3), "storage": a.dtype}
         roof["whole_step"] = whole_step_roofline(a, 1e3 * dt / a.steps)
         infer = None
         if world == 1 and not a.no_inference_leg and (a.height, a.width, a.batch) == (400, 600, 8):
@@ -314,10 +347,11 @@ def main():
                       + " + bwd + grad all-reduce + Adam)",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if a.dtype == "f32" else "bf16 storage of the IEL hidden tensors, f32 arithmetic", "data": "synthetic",
             "config": {"workload": f"CIDNet fwd+bwd bs={a.batch}/GPU 3x{a.height}x{a.width} fp32 (BASELINE.json configs[1])",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
-            "roofline": roof, "cpu_baseline": cpu, "inference_1024": infer,
+            "roofline": roof if a.dtype == "f32" else dict(roof_hbm, mfma_conv3=roof), "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
+            "inference_1024": infer,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

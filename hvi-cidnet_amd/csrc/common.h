@@ -46,6 +46,42 @@ __device__ __forceinline__ void store4u(float* p, f32x4 v) {
   *reinterpret_cast<f4u*>(p) = s;
 }
 
+// ---- bf16 storage (row J1: activations / saved tensors may be stored as bf16; all arithmetic stays fp32) ------------
+// Element type codes of the C ABI (include/cidnet_hip.h): CIDNET_F32 = 0, CIDNET_BF16 = 1.  A tensor's type is a
+// kernel argument (wave-uniform), so one kernel serves both; the branch is scalar.
+typedef unsigned short bf16_t;
+struct __attribute__((packed, aligned(2))) h4u { bf16_t x, y, z, w; };
+struct __attribute__((packed, aligned(2))) h2u { bf16_t x, y; };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {          // round to nearest even; v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+// 4 consecutive elements at element offset `off` of a tensor whose type is `dt`
+__device__ __forceinline__ f32x4 ld4t(const void* base, long off, int dt) {
+  if (dt) {
+    const h4u v = *reinterpret_cast<const h4u*>(reinterpret_cast<const bf16_t*>(base) + off);
+    return f32x4{bf16_to_f32(v.x), bf16_to_f32(v.y), bf16_to_f32(v.z), bf16_to_f32(v.w)};
+  }
+  return load4u(reinterpret_cast<const float*>(base) + off);
+}
+__device__ __forceinline__ void st4t(void* base, long off, int dt, f32x4 v) {
+  if (dt) {
+    h4u s;
+    s.x = f32_to_bf16(v[0]); s.y = f32_to_bf16(v[1]); s.z = f32_to_bf16(v[2]); s.w = f32_to_bf16(v[3]);
+    *reinterpret_cast<h4u*>(reinterpret_cast<bf16_t*>(base) + off) = s;
+  } else {
+    store4u(reinterpret_cast<float*>(base) + off, v);
+  }
+}
+__device__ __forceinline__ float ld1t(const void* base, long off, int dt) {
+  return dt ? bf16_to_f32(reinterpret_cast<const bf16_t*>(base)[off]) : reinterpret_cast<const float*>(base)[off];
+}
+__device__ __forceinline__ void st1t(void* base, long off, int dt, float v) {
+  if (dt) reinterpret_cast<bf16_t*>(base)[off] = f32_to_bf16(v);
+  else reinterpret_cast<float*>(base)[off] = v;
+}
+
 // tanh on the hardware exp2 / rcp units (about 10 VALU ops instead of the library's ~50): 1 - 2/(e^{2x} + 1) away
 // from zero, the odd Taylor polynomial through x^7 for |x| < 0.2 where that form cancels.  Absolute error < 1.5e-7.
 __device__ __forceinline__ float tanh_fast(float x) {

@@ -189,10 +189,10 @@ __global__ __launch_bounds__(kThreads) void iel_gate_kernel(const float* __restr
 // next; here a lane slides a 3-row, 8-wide window of pin down its strip, forms each row of u on a 6-wide window
 // (own 4 pixels + the 1-pixel halo the gate's convolutions need), stores its own 4 pixels of u (the backward needs u)
 // and the gate row.  HBM traffic: read pin (2h), write u (2h) and g (h): 5h instead of 7h planes.
-template <bool NARROW>
-__global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const float* __restrict__ pin, const float* __restrict__ wdw,
+template <bool NARROW, class T>      // T: storage type of the hidden tensors pin, u, g (float, or bf16_t in the bf16 storage mode)
+__global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const T* __restrict__ pin, const float* __restrict__ wdw,
                                                                const float* __restrict__ w1, const float* __restrict__ w2,
-                                                               float* __restrict__ u, float* __restrict__ g, int B, int h, int H,
+                                                               T* __restrict__ u, T* __restrict__ g, int B, int h, int H,
                                                                int W, Tiling tl) {
   const Item it = decode_item<NARROW>((long)B * h, tl, W);
   if (!it.live) return;
@@ -205,11 +205,11 @@ __global__ __launch_bounds__(kThreads) void iel_dw_gate_kernel(const float* __re
     wa[t] = w1[(long)c * 9 + t]; wb[t] = w2[(long)c * 9 + t];
   }
   const long HW = (long)H * W;
-  const float* p1 = pin + (b * 2 * h + c) * HW;
-  const float* p2 = pin + (b * 2 * h + h + c) * HW;
-  float* u1 = u + (b * 2 * h + c) * HW;
-  float* u2 = u + (b * 2 * h + h + c) * HW;
-  float* gp = g + it.bc * HW;
+  const T* p1 = pin + (b * 2 * h + c) * HW;
+  const T* p2 = pin + (b * 2 * h + h + c) * HW;
+  T* u1 = u + (b * 2 * h + c) * HW;
+  T* u2 = u + (b * 2 * h + h + c) * HW;
+  T* gp = g + it.bc * HW;
   const int x0 = it.x0, y0 = it.y0, yend = min(y0 + tl.rows, H);
   // u on the columns x0-1 .. x0+4 of row r, from pin rows r-1, r, r+1 (8-wide); zero outside the image
   auto u_row = [&](const Win8& a, const Win8& m, const Win8& z, const float (&w)[9], int r) {
@@ -319,18 +319,18 @@ __global__ __launch_bounds__(kThreads) void dw3x3_wgrad_kernel(const float* __re
 //   gin[y][x] = sum_tap w[8-tap] * gout[y+dy-1][x+dx-1]  (+ addend)
 // and the per-block partial of the weight gradient gw[tap] = sum gout[y][x] * in[y+dy-1][x+dx-1]:
 // gout is read once instead of twice (3 tensor passes instead of 4).
-template <bool NARROW>
-__global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+template <bool NARROW, class T>      // T: storage type of in, gout, addend, gin
+__global__ __launch_bounds__(kThreads) void dw3x3_bwd_kernel(const T* __restrict__ in, const T* __restrict__ gout,
                                                              const float* __restrict__ w1, const float* __restrict__ w2, int csplit,
-                                                             const float* __restrict__ addend, float* __restrict__ gin,
+                                                             const T* __restrict__ addend, T* __restrict__ gin,
                                                              float* __restrict__ part, int C, int H, int W, int nchunk, Tiling tl) {
   __shared__ float red[kThreads / 64];
   const long bc = blockIdx.y;
   const long HW = (long)H * W;
-  const float* ip = in + bc * HW;
-  const float* gp = gout + bc * HW;
-  const float* ap = addend ? addend + bc * HW : nullptr;
-  float* op = gin + bc * HW;
+  const T* ip = in + bc * HW;
+  const T* gp = gout + bc * HW;
+  const T* ap = addend ? addend + bc * HW : nullptr;
+  T* op = gin + bc * HW;
   float w[9];
   load_w9(w1, w2, csplit, (int)(bc % C), true, w);
   float acc[9];
@@ -415,21 +415,21 @@ __device__ __forceinline__ GateRow gate_bwd_row(const Win8& a0, const Win8& a1, 
   return o;
 }
 
-template <bool NARROW>
-__global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const float* __restrict__ u, const float* __restrict__ w1,
-                                                                   const float* __restrict__ w2, const float* __restrict__ dg,
-                                                                   float* __restrict__ du, float* __restrict__ part, int h, int H,
+template <bool NARROW, class T>      // T: storage type of u, dg, du
+__global__ __launch_bounds__(kThreads) void iel_gate_dw_bwd_kernel(const T* __restrict__ u, const float* __restrict__ w1,
+                                                                   const float* __restrict__ w2, const T* __restrict__ dg,
+                                                                   T* __restrict__ du, float* __restrict__ part, int h, int H,
                                                                    int W, int nchunk, Tiling tl) {
   __shared__ float red[kThreads / 64];
   const long bc = blockIdx.y;                    // b * h + c
   const int c = (int)(bc % h);
   const long b = bc / h;
   const long HW = (long)H * W;
-  const float* p1 = u + (b * 2 * h + c) * HW;
-  const float* p2 = u + (b * 2 * h + h + c) * HW;
-  const float* gp = dg + bc * HW;
-  float* o1 = du + (b * 2 * h + c) * HW;
-  float* o2 = du + (b * 2 * h + h + c) * HW;
+  const T* p1 = u + (b * 2 * h + c) * HW;
+  const T* p2 = u + (b * 2 * h + h + c) * HW;
+  const T* gp = dg + bc * HW;
+  T* o1 = du + (b * 2 * h + c) * HW;
+  T* o2 = du + (b * 2 * h + h + c) * HW;
   float wa[9], wb[9], fa[9], fb[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -580,6 +580,12 @@ using namespace cidnet;
 
 extern "C" {
 
+int cidnet_dw3x3_bwd_t(const void* in, const void* gout, const float* w1, const float* w2, int csplit, const void* addend,
+                       void* gin, int dt, float* gw1, float* gw2, float* ws, long ws_floats, int B, int C, int H, int W,
+                       void* stream);
+int cidnet_iel_gate_dw_bwd_t(const void* u, const float* w1, const float* w2, const void* dg, void* du, int dt, float* gw1,
+                             float* gw2, float* ws, long ws_floats, int B, int h, int H, int W, void* stream);
+
 #ifdef CIDNET_DEBUG
 void cidnet_debug_dw_rows(int rows) { g_dw_force_rows = rows; }
 #endif
@@ -607,15 +613,25 @@ int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float*
   return CIDNET_OK;
 }
 
-int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g, int B, int h,
-                           int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(pin && wdw && w1 && w2 && g && B > 0 && h > 0 && H > 0 && W > 0);   // u may be NULL (not stored)
+int cidnet_iel_dw_gate_fwd_t(const void* pin, const float* wdw, const float* w1, const float* w2, void* u, void* g, int dt, int B,
+                             int h, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(pin && wdw && w1 && w2 && g && B > 0 && h > 0 && H > 0 && W > 0 && (dt | 1) == 1);   // u may be NULL (not stored)
   const Tiling tl = dw_gate_tiling((long)B * h, H, W);
   const long items = n_items((long)B * h, tl);
-  CIDNET_LAUNCH_NW(W, (iel_dw_gate_kernel<true>), (iel_dw_gate_kernel<false>), dim3((unsigned)((items + kThreads - 1) / kThreads)),
-                   dim3(kThreads), 0, (hipStream_t)stream, pin, wdw, w1, w2, u, g, B, h, H, W, tl);
+  const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+  if (dt)
+    CIDNET_LAUNCH_NW(W, (iel_dw_gate_kernel<true, bf16_t>), (iel_dw_gate_kernel<false, bf16_t>), grid, dim3(kThreads), 0,
+                     (hipStream_t)stream, (const bf16_t*)pin, wdw, w1, w2, (bf16_t*)u, (bf16_t*)g, B, h, H, W, tl);
+  else
+    CIDNET_LAUNCH_NW(W, (iel_dw_gate_kernel<true, float>), (iel_dw_gate_kernel<false, float>), grid, dim3(kThreads), 0,
+                     (hipStream_t)stream, (const float*)pin, wdw, w1, w2, (float*)u, (float*)g, B, h, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g, int B, int h,
+                           int H, int W, void* stream) {
+  return cidnet_iel_dw_gate_fwd_t(pin, wdw, w1, w2, u, g, 0, B, h, H, W, stream);
 }
 
 int cidnet_iel_gate_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* da, float* ds, int B,
@@ -653,13 +669,25 @@ int cidnet_dw3x3_wgrad(const float* in, const float* gout, float* gw1, float* gw
  * [+ addend]; gw = sum gout * shifted(in).  ws as cidnet_dw3x3_wgrad. */
 int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const float* w2, int csplit, const float* addend,
                      float* gin, float* gw1, float* gw2, float* ws, long ws_floats, int B, int C, int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(in && gout && w1 && gin && gw1 && ws && B > 0 && C > 0 && H > 0 && W > 0);
+  return cidnet_dw3x3_bwd_t(in, gout, w1, w2, csplit, addend, gin, 0, gw1, gw2, ws, ws_floats, B, C, H, W, stream);
+}
+
+int cidnet_dw3x3_bwd_t(const void* in, const void* gout, const float* w1, const float* w2, int csplit, const void* addend,
+                       void* gin, int dt, float* gw1, float* gw2, float* ws, long ws_floats, int B, int C, int H, int W,
+                       void* stream) {
+  CIDNET_CHECK_ARG(in && gout && w1 && gin && gw1 && ws && B > 0 && C > 0 && H > 0 && W > 0 && (dt | 1) == 1);
   CIDNET_CHECK_ARG(csplit >= C || (w2 && gw2));
   if (ws_floats < cidnet_dw3x3_wgrad_ws_floats(B, C, H, W)) return CIDNET_ERR_WS;
   const Tiling tl = wgrad_tiling((long)B * C, H, W);
   const int nchunk = (chunks_of(tl) + kSub - 1) / kSub;
-  CIDNET_LAUNCH_NW(W, (dw3x3_bwd_kernel<true>), (dw3x3_bwd_kernel<false>), dim3((unsigned)nchunk, (unsigned)(B * C)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, in, gout,
-                     w1, w2, csplit, addend, gin, ws, C, H, W, nchunk, tl);
+  if (dt)
+    CIDNET_LAUNCH_NW(W, (dw3x3_bwd_kernel<true, bf16_t>), (dw3x3_bwd_kernel<false, bf16_t>), dim3((unsigned)nchunk, (unsigned)(B * C)),
+                     dim3(plane_threads(tl)), 0, (hipStream_t)stream, (const bf16_t*)in, (const bf16_t*)gout, w1, w2, csplit,
+                     (const bf16_t*)addend, (bf16_t*)gin, ws, C, H, W, nchunk, tl);
+  else
+    CIDNET_LAUNCH_NW(W, (dw3x3_bwd_kernel<true, float>), (dw3x3_bwd_kernel<false, float>), dim3((unsigned)nchunk, (unsigned)(B * C)),
+                     dim3(plane_threads(tl)), 0, (hipStream_t)stream, (const float*)in, (const float*)gout, w1, w2, csplit,
+                     (const float*)addend, (float*)gin, ws, C, H, W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, C,
                      nchunk, gw1, gw2, csplit);
@@ -675,12 +703,23 @@ long cidnet_iel_gate_dw_bwd_ws_floats(int B, int h, int H, int W) {
  * pass: reads dg (B,h,H,W) and u (B,2h,H,W), writes du (B,2h,H,W), gw1/gw2 (h,1,3,3). */
 int cidnet_iel_gate_dw_bwd(const float* u, const float* w1, const float* w2, const float* dg, float* du, float* gw1, float* gw2,
                            float* ws, long ws_floats, int B, int h, int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(u && w1 && w2 && dg && du && gw1 && gw2 && ws && B > 0 && h > 0 && H > 0 && W > 0);
+  return cidnet_iel_gate_dw_bwd_t(u, w1, w2, dg, du, 0, gw1, gw2, ws, ws_floats, B, h, H, W, stream);
+}
+
+int cidnet_iel_gate_dw_bwd_t(const void* u, const float* w1, const float* w2, const void* dg, void* du, int dt, float* gw1,
+                             float* gw2, float* ws, long ws_floats, int B, int h, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(u && w1 && w2 && dg && du && gw1 && gw2 && ws && B > 0 && h > 0 && H > 0 && W > 0 && (dt | 1) == 1);
   if (ws_floats < cidnet_iel_gate_dw_bwd_ws_floats(B, h, H, W)) return CIDNET_ERR_WS;
   const Tiling tl = gate_bwd_tiling((long)B * h, H, W);
   const int nchunk = (chunks_of(tl) + kSub - 1) / kSub;
-  CIDNET_LAUNCH_NW(W, (iel_gate_dw_bwd_kernel<true>), (iel_gate_dw_bwd_kernel<false>), dim3((unsigned)nchunk, (unsigned)(B * h)), dim3(plane_threads(tl)), 0, (hipStream_t)stream, u,
-                     w1, w2, dg, du, ws, h, H, W, nchunk, tl);
+  if (dt)
+    CIDNET_LAUNCH_NW(W, (iel_gate_dw_bwd_kernel<true, bf16_t>), (iel_gate_dw_bwd_kernel<false, bf16_t>), dim3((unsigned)nchunk, (unsigned)(B * h)),
+                     dim3(plane_threads(tl)), 0, (hipStream_t)stream, (const bf16_t*)u, w1, w2, (const bf16_t*)dg, (bf16_t*)du, ws, h, H,
+                     W, nchunk, tl);
+  else
+    CIDNET_LAUNCH_NW(W, (iel_gate_dw_bwd_kernel<true, float>), (iel_gate_dw_bwd_kernel<false, float>), dim3((unsigned)nchunk, (unsigned)(B * h)),
+                     dim3(plane_threads(tl)), 0, (hipStream_t)stream, (const float*)u, w1, w2, (const float*)dg, (float*)du, ws, h, H,
+                     W, nchunk, tl);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((h * 18 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, B, h,
                      nchunk, gw1, gw2);

