@@ -359,7 +359,7 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_TRAFFIC_FILE = "profiles/r01_pmc_conv3_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_conv3_traffic.json"
 
 
 def pmc_traffic():
