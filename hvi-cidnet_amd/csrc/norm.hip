@@ -258,8 +258,10 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float
 }
 
 // gw[c], gb[c] = sum over blocks of part[blk][c], part[blk][C + c]: 8 outputs per block, 32 lanes per output
+// accumulate != 0: gw / gb += the sums (a LayerNorm module applied several times per step adds up its uses' gradients
+// in place, in backward order, instead of through separate autograd accumulation launches)
 __global__ __launch_bounds__(256) void ln_wb2_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ gw,
-                                                            float* __restrict__ gb) {
+                                                            float* __restrict__ gb, int accumulate) {
   __shared__ float fold[32][9];
   const int ex = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int i = blockIdx.x * 8 + ex;
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(256) void ln_wb2_reduce_kernel(const float* __restr
 #pragma unroll
     for (int g = 0; g < 8; ++g) v[g] = (fold[4 * g][ex] + fold[4 * g + 1][ex]) + (fold[4 * g + 2][ex] + fold[4 * g + 3][ex]);
     const float tot = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    if (i < C) gw[i] = tot; else gb[i - C] = tot;
+    float* dst = i < C ? gw + i : gb + (i - C);
+    *dst = accumulate ? *dst + tot : tot;
   }
 }
 
@@ -377,12 +380,13 @@ __global__ __launch_bounds__(kThreads) void ln_wb_kernel(const float* __restrict
 }
 
 __global__ void ln_wb_reduce_kernel(const float* __restrict__ part, int nchunk, int C, float* __restrict__ gw,
-                                    float* __restrict__ gb) {
+                                    float* __restrict__ gb, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
   for (int k = 0; k < nchunk; ++k) { a += part[((long)c * nchunk + k) * 2]; b += part[((long)c * nchunk + k) * 2 + 1]; }
-  gw[c] = a; gb[c] = b;
+  gw[c] = accumulate ? gw[c] + a : a;
+  gb[c] = accumulate ? gb[c] + b : b;
 }
 
 inline int grid_for(long items) {
@@ -435,8 +439,8 @@ long cidnet_ln_cf_bwd_ws_floats(int C) {
 }
 
 int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd,
-                         const float* addend, float* gx, float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW,
-                         void* stream) {
+                         const float* addend, float* gx, float* gw, float* gb, int accumulate, float* ws, long ws_floats, int B,
+                         int C, long HW, void* stream) {
   CIDNET_CHECK_ARG(x && weight && gy && mean && rstd && gw && gb && ws && B > 0 && C > 0 && HW > 0);
   const int nchunk = wb_chunks(B, C, HW);
   if (ws_floats < 2L * C * nchunk) return CIDNET_ERR_WS;
@@ -457,7 +461,7 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
       hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 1, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
                          ws, B, HW);
     CIDNET_LAUNCH_STATUS();
-    hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb);
+    hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb, accumulate);
     CIDNET_LAUNCH_STATUS();
     return CIDNET_OK;
   }
@@ -482,14 +486,14 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
   hipLaunchKernelGGL(ln_wb_kernel, dim3((unsigned)nchunk, (unsigned)C), dim3(kThreads), 0, s, x, gy, mean, rstd, ws, B, C, HW,
                      nchunk);
   CIDNET_LAUNCH_STATUS();
-  hipLaunchKernelGGL(ln_wb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nchunk, C, gw, gb);
+  hipLaunchKernelGGL(ln_wb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, nchunk, C, gw, gb, accumulate);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
 
 int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd, float* gx,
                      float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW, void* stream) {
-  return cidnet_ln_cf_bwd_res(x, weight, gy, mean, rstd, nullptr, gx, gw, gb, ws, ws_floats, B, C, HW, stream);
+  return cidnet_ln_cf_bwd_res(x, weight, gy, mean, rstd, nullptr, gx, gw, gb, 0, ws, ws_floats, B, C, HW, stream);
 }
 
 }  // extern "C"

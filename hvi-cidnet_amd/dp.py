@@ -122,10 +122,13 @@ class DataParallelTrainer:
                     order.append(_p)
                 fired[id(_p)] += 1
             hooks.append(p.register_post_accumulate_grad_hook(h))
+        ln_uses = [m._use for m in self.model.modules() if hasattr(m, "_use")] if self.use_hip else []
         if self.use_hip:
             from . import ops
             ops.set_grad_arena(None, None)
             ops.start_grad_probe()
+            for st in ln_uses:
+                st.acc, st.fwd, st.bwd, st.probe = False, 0, 0, [0, 0]
         self.model.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model(x), gt)
         loss.backward()
@@ -135,8 +138,17 @@ class DataParallelTrainer:
         # 3 uses per LCA) must be summed by autograd, not written in place
         counts = ops.stop_grad_probe() if self.use_hip else {}
         multi_ids = {id(p) for p in self.params if counts.get(p.data_ptr(), 0) > 1}
+        # LayerNorm modules applied several times per step whose every forward use came back in the probing backward: their
+        # uses sum the weight / bias gradients in place in the arena (ops.LNUse), so they count as arena parameters
+        ln_acc_ids = set()
+        for m in (self.model.modules() if self.use_hip else ()):
+            st = getattr(m, "_use", None)
+            if st is not None and st.probe[0] > 0 and st.probe[0] == st.probe[1]:
+                st.acc, st.fwd, st.bwd = True, 0, 0
+                ln_acc_ids.update((id(m.weight), id(m.bias)))
+        multi_ids -= ln_acc_ids
         # single-use parameters whose gradient a kernel writes in place into the arena, possibly on the weight-gradient stream
-        self._arena_ids = {id(p) for p in self.params if counts.get(p.data_ptr(), 0) == 1}
+        self._arena_ids = {id(p) for p in self.params if counts.get(p.data_ptr(), 0) == 1} | ln_acc_ids
         self.model.zero_grad(set_to_none=True)
         live = order
         dead = [p for p in self.params if id(p) not in fired]

@@ -304,11 +304,52 @@ def prelu_bwd(go, pre, slope):
 # --------------------------------------------------------------------------------------------
 # K3: LayerNorm (channels first)
 # --------------------------------------------------------------------------------------------
+class LNUse:
+    """Per-module bookkeeping for a LayerNorm that is applied several times per step (net/LCA.py:79-80,91-92: one `norm`
+    per LCA, used on x, on y and on the CAB output).  With `acc` set (by dp.DataParallelTrainer, after its probing step has
+    seen every forward use come back in the backward) the uses sum their weight / bias gradients IN PLACE in the gradient
+    arena -- the first backward use overwrites, the others add (cidnet_ln_cf_bwd_res, accumulate) -- and only the last one
+    hands the arena views to autograd: no separate accumulation launches (44 per step) and no copies into the arena (22)."""
+
+    def __init__(self):
+        self.fwd = 0          # uses in the current forward pass
+        self.bwd = 0          # of which have run their backward
+        self.acc = False
+        self.probe = [0, 0]   # forward / backward uses counted while not in acc mode (the trainer's probe reads them)
+
+
+def _ln_param_grads(ctx, weight, bias):
+    """-> (gw, gb, accumulate, hand_over): the tensors the kernel writes, whether it adds, whether autograd gets them"""
+    st = ctx.ln_state
+    if st is not None and st.acc and _ARENA is not None:
+        gw, gb = grad_like(weight), grad_like(bias)
+        if _in_arena(gw) and _in_arena(gb):
+            first = st.bwd == 0
+            st.bwd += 1
+            last = st.bwd >= st.fwd
+            if last:
+                st.fwd = st.bwd = 0
+            return gw, gb, (not first), last
+    if st is not None:
+        st.probe[1] += 1
+    return grad_like(weight), torch.empty_like(weight), False, True
+
+
+def _ln_forward_count(ctx, state):
+    """`state` is None unless a backward will follow (decided by the module: ops.needs_grad)"""
+    ctx.ln_state = state
+    if state is not None:
+        if state.acc:
+            state.fwd += 1
+        else:
+            state.probe[0] += 1
+
+
 class LayerNormCFFn(torch.autograd.Function):
     """Reference: LayerNorm.forward (channels_first), net/transformer_utils.py:24-29."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, state=None):
         _check(x, weight, bias)
         x = _c(x)
         B, C, H, W = x.shape
@@ -316,22 +357,22 @@ class LayerNormCFFn(torch.autograd.Function):
         mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         lib().call("cidnet_ln_cf_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
-        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        _ln_forward_count(ctx, state)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, mean, rstd = ctx.saved_tensors
+        x, weight, bias, mean, rstd = ctx.saved_tensors
         B, C, H, W = x.shape
         gy = _c(gy)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gw = grad_like(weight)
-        gb = torch.empty_like(weight)
+        gw, gb, acc, hand = _ln_param_grads(ctx, weight, bias)
         n = _raw("cidnet_ln_cf_bwd_ws_floats", C)
         ws = _ws(n, x.device)
-        lib().call("cidnet_ln_cf_bwd", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), _p(gx), _p(gw), _p(gb), _p(ws), ws.numel(),
-                   B, C, H * W, _stream())
-        return gx, gw, gb, None
+        lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), None, _p(gx), _p(gw), _p(gb), int(acc), _p(ws),
+                   ws.numel(), B, C, H * W, _stream())
+        return gx, (gw if hand else None), (gb if hand else None), None, None
 
 
 class LayerNormResFn(torch.autograd.Function):
@@ -341,7 +382,7 @@ class LayerNormResFn(torch.autograd.Function):
     (cidnet_ln_cf_bwd_res)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, state=None):
         _check(x, weight, bias)
         x = _c(x)
         B, C, H, W = x.shape
@@ -349,26 +390,27 @@ class LayerNormResFn(torch.autograd.Function):
         mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         lib().call("cidnet_ln_cf_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
-        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        _ln_forward_count(ctx, state)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, gy, gres):
-        x, weight, mean, rstd = ctx.saved_tensors
+        x, weight, bias, mean, rstd = ctx.saved_tensors
         B, C, H, W = x.shape
-        gw = grad_like(weight)
-        gb = torch.empty_like(weight)
+        gw, gb, acc, hand = _ln_param_grads(ctx, weight, bias)
         if gy is None:                      # only the residual path was used
-            gw.zero_(); gb.zero_()
-            return gres, gw, gb, None
+            if not acc:
+                gw.zero_(); gb.zero_()
+            return gres, (gw if hand else None), (gb if hand else None), None, None
         gy = _c(gy)
         gres = _c(gres) if gres is not None else None
         gx = torch.empty_like(x)
         n = _raw("cidnet_ln_cf_bwd_ws_floats", C)
         ws = _ws(n, x.device)
-        lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw), _p(gb), _p(ws),
-                   ws.numel(), B, C, H * W, _stream())
-        return gx, gw, gb, None
+        lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw), _p(gb), int(acc),
+                   _p(ws), ws.numel(), B, C, H * W, _stream())
+        return gx, (gw if hand else None), (gb if hand else None), None, None
 
 
 # --------------------------------------------------------------------------------------------

@@ -19,18 +19,21 @@ class LayerNorm(nn.Module):
         if self.data_format not in ["channels_last", "channels_first"]:
             raise NotImplementedError
         self.normalized_shape = (normalized_shape,)
+        self._use = ops.LNUse()            # multi-use bookkeeping (ops.LNUse): in-place summing of this module's gradients
 
     def forward(self, x):
         if self.data_format != "channels_first":
             raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
-        return ops.LayerNormCFFn.apply(x, self.weight, self.bias, self.eps)
+        return ops.LayerNormCFFn.apply(x, self.weight, self.bias, self.eps,
+                                       self._use if ops.needs_grad(x, self.weight, self.bias) else None)
 
     def forward_res(self, x):
         """(norm(x), x) for a pre-norm residual block: use the second value as the residual input (see
         ops.LayerNormResFn: the residual's gradient is then added inside the LayerNorm backward kernel)."""
         if self.data_format != "channels_first":
             raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
-        return ops.LayerNormResFn.apply(x, self.weight, self.bias, self.eps)
+        return ops.LayerNormResFn.apply(x, self.weight, self.bias, self.eps,
+                                        self._use if ops.needs_grad(x, self.weight, self.bias) else None)
 
 
 class NormDownsample(nn.Module):

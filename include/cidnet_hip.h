@@ -71,10 +71,12 @@ int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const
                      const float* rstd, float* gx, float* gw, float* gb, float* ws, long ws_floats,
                      int B, int C, long HW, void* stream);
 /* same, with gx += addend (the gradient that reaches x through the residual branch of the pre-norm block,
- * net/LCA.py:79,80,91,92): saves the separate accumulation pass.  addend may be NULL. */
+ * net/LCA.py:79,80,91,92): saves the separate accumulation pass.  addend may be NULL.  accumulate != 0: gw / gb are
+ * added to instead of overwritten -- one LayerNorm module is applied two or three times per LCA (LCA.py:79-80,91-92)
+ * and its uses then sum their parameter gradients in place, in backward order. */
 int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd,
-                         const float* addend, float* gx, float* gw, float* gb, float* ws, long ws_floats, int B, int C,
-                         long HW, void* stream);
+                         const float* addend, float* gx, float* gw, float* gb, int accumulate, float* ws,
+                         long ws_floats, int B, int C, long HW, void* stream);
 
 /* ---- K4: pointwise (1x1) convolution on the fp32 MFMA -----------------------------------------
  * (nn.Conv2d(k=1): net/LCA.py:13,15,17,51,57; net/transformer_utils.py:60)

@@ -53,6 +53,11 @@ def test_trainer_gradients_and_update_match_plain_autograd(dev, chans, shape):
         assert err <= tol, f"{n}: {err:.3e} > {tol:.3e}"
         checked += 1
     assert checked > 150
+    # LayerNorm modules used several times per step sum their gradients in place in the arena (ops.LNUse): every live
+    # norm is in that mode after the probe, the dead I_LCA5.norm is not, and the counters are back at rest
+    uses = {n: mod._use for n, mod in m.named_modules() if hasattr(mod, "_use")}
+    assert len(uses) == 12 and all(st.acc == (not n.startswith("I_LCA5")) for n, st in uses.items()), {n: st.acc for n, st in uses.items()}
+    assert all(st.fwd == 0 and st.bwd == 0 for st in uses.values())
     # one full step == torch Adam fed with the harness's own gradients.  (Fed with the plain-autograd gradients
     # instead, first-step Adam ~ lr * g / (|g| + eps) amplifies summation-order noise on elements with
     # |g| ~ eps into differences of the order of lr, so that comparison would test luck.)
