@@ -120,6 +120,45 @@ class CIDNet(nn.Module, _HubMixin):
                 t.record_stream(main)
         return out_i, out_hv
 
+    # An LCA pair (net/CIDNet.py:83-84 etc.): I_LCA(i, hv) and HV_LCA(hv, i).  Each of the two inputs feeds three consumers --
+    # the x-norm of its own block (which also hands it on as the CAB residual) and the y-norm of the other block -- and
+    # autograd would sum their gradients with separate passes over the tensor (ten per step).  With `chain_lca_inputs` the
+    # input is threaded through the norms instead: t -> HV.norm -> (n, t1) -> I.norm -> (n', t2) -> residual consumer, every
+    # link being ops.LayerNormResFn whose backward kernel adds the gradient that arrives for its pass-through output.  Each
+    # module's norm still runs on its own branch's stream (the in-place summing of LayerNorm parameter gradients relies on
+    # that), and the forward needs no extra synchronisation: t1 / t2 are views of t.
+    chain_lca_inputs = True
+
+    def _lca_pair(self, I_blk, HV_blk, i, hv):
+        if not (self.chain_lca_inputs and torch.is_grad_enabled() and (i.requires_grad or hv.requires_grad)):
+            return self._par(lambda: I_blk(i, hv), lambda: HV_blk(hv, i), (i, hv))
+        two = self.two_streams and i.is_cuda
+        main = side = None
+        if two:
+            main = torch.cuda.current_stream()
+            side = getattr(self, "_side_stream", None)
+            if side is None or side.device != i.device:
+                side = torch.cuda.Stream(device=i.device)
+                object.__setattr__(self, "_side_stream", side)
+            side.wait_stream(main)
+
+        def on_side(f):
+            if not two:
+                return f()
+            with torch.cuda.stream(side):
+                return f()
+        (hv_nhv, hv1), (i_nhv, i1) = on_side(lambda: (HV_blk.norm.forward_res(hv), HV_blk.norm.forward_res(i)))
+        i_ni, i2 = I_blk.norm.forward_res(i1)
+        hv_ni, hv2 = I_blk.norm.forward_res(hv1)
+        out_hv = on_side(lambda: HV_blk.body(hv_nhv, i_nhv, hv2))
+        out_i = I_blk.body(i_ni, hv_ni, i2)
+        if two:
+            main.wait_stream(side)
+            for t in (i, hv):
+                t.record_stream(side)
+            out_hv.record_stream(main)
+        return out_i, out_hv
+
     # Back-pressure for callers that drive model(x) / backward() themselves (the trainer has its own): the host enqueues a
     # forward+backward about twice as fast as the GPU runs it, and every queued pass pins several GiB in the caching
     # allocator (cross-stream frees wait for their events), which ends in hipMalloc storms and multi-second stalls once
@@ -154,17 +193,16 @@ class CIDNet(nn.Module, _HubMixin):
         i_jump0 = i_enc0
         hv_jump0 = hv_0
 
-        i_enc2, hv_2 = self._par(lambda: self.I_LCA1(i_enc1, hv_1), lambda: self.HV_LCA1(hv_1, i_enc1), (i_enc1, hv_1))
+        i_enc2, hv_2 = self._lca_pair(self.I_LCA1, self.HV_LCA1, i_enc1, hv_1)
         (v_jump1, i_enc2), (hv_jump1, hv_2) = self._par(lambda: self._down_skip(self.IE_block2, i_enc2),
                                                         lambda: self._down_skip(self.HVE_block2, hv_2), (i_enc2, hv_2))
 
         # reference quirk: level-3 encoders take the PRE-LCA2 tensors (net/CIDNet.py:94-95)
-        (v_jump2, i_enc3), (hv_jump2, hv_3) = self._par(
-            lambda: (self.I_LCA2(i_enc2, hv_2), self.IE_block3(i_enc2)),
-            lambda: (self.HV_LCA2(hv_2, i_enc2), self.HVE_block3(hv_2)), (i_enc2, hv_2))
+        v_jump2, hv_jump2 = self._lca_pair(self.I_LCA2, self.HV_LCA2, i_enc2, hv_2)
+        i_enc3, hv_3 = self._par(lambda: self.IE_block3(i_enc2), lambda: self.HVE_block3(hv_2), (i_enc2, hv_2))
 
-        i_enc4, hv_4 = self._par(lambda: self.I_LCA3(i_enc3, hv_3), lambda: self.HV_LCA3(hv_3, i_enc3), (i_enc3, hv_3))
-        i_dec4, hv_4b = self._par(lambda: self.I_LCA4(i_enc4, hv_4), lambda: self.HV_LCA4(hv_4, i_enc4), (i_enc4, hv_4))
+        i_enc4, hv_4 = self._lca_pair(self.I_LCA3, self.HV_LCA3, i_enc3, hv_3)
+        i_dec4, hv_4b = self._lca_pair(self.I_LCA4, self.HV_LCA4, i_enc4, hv_4)
 
         i_dec3, hv_3 = self._par(lambda: self._gate("sa_i3", self.ID_block3(i_dec4, v_jump2)),
                                  lambda: self._gate("sa_hv3", self.HVD_block3(hv_4b, hv_jump2)),
@@ -175,7 +213,7 @@ class CIDNet(nn.Module, _HubMixin):
                                  lambda: self._gate("sa_hv2", self.HVD_block2(hv_2, hv_jump1)),
                                  (i_dec2, hv_2, v_jump1, hv_jump1))
 
-        i_dec1, hv_1 = self._par(lambda: self.I_LCA6(i_dec2, hv_2), lambda: self.HV_LCA6(hv_2, i_dec2), (i_dec2, hv_2))
+        i_dec1, hv_1 = self._lca_pair(self.I_LCA6, self.HV_LCA6, i_dec2, hv_2)
 
         i_dec0, hv_0 = self._par(
             lambda: self.ID_block0(self._gate("sa_i1", self.ID_block1(i_dec1, i_jump0))),

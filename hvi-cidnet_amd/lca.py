@@ -64,7 +64,11 @@ class HV_LCA(nn.Module):
 
     def forward(self, x, y):
         xn, xr = self.norm.forward_res(x)          # xr is x: the residual's gradient is added inside the LN backward
-        x = self.ffn(xn, self.norm(y), residual=xr)
+        return self.body(xn, self.norm(y), xr)
+
+    def body(self, xn, yn, xr):
+        """the block after its two input norms: xn = norm(x), yn = norm(y), xr = x as the residual input"""
+        x = self.ffn(xn, yn, residual=xr)
         return self.gdfn(self.norm(x))
 
 
@@ -79,6 +83,10 @@ class I_LCA(nn.Module):
 
     def forward(self, x, y):
         xn, xr = self.norm.forward_res(x)          # xr is x: the residual's gradient is added inside the LN backward
-        x = self.ffn(xn, self.norm(y), residual=xr)
+        return self.body(xn, self.norm(y), xr)
+
+    def body(self, xn, yn, xr):
+        """the block after its two input norms: xn = norm(x), yn = norm(y), xr = x as the residual input"""
+        x = self.ffn(xn, yn, residual=xr)
         xn, xr = self.norm.forward_res(x)
         return self.gdfn(xn, residual=xr)
