@@ -98,10 +98,16 @@ class CIDNet(nn.Module, _HubMixin):
     # ---- two-stream execution: the I branch and the HV branch of every stage are independent ----
     two_streams = True
 
+    def _two(self, t):
+        # The opt-in bf16x3 conv (ops.CONV3_BF16X3, csrc/conv3s.hip) must not share a CU with the other branch's kernels:
+        # next to its waves the packed-fp32 FMAs of the stem conv drop single products (tools/c3s_batch_probe.py, DESIGN.md
+        # section 4), so that mode runs the two branches one after the other.
+        return self.two_streams and t.is_cuda and not ops.CONV3_BF16X3["on"]
+
     def _par(self, f_i, f_hv, shared):
         """Run f_i on the current stream and f_hv on a side stream, then join.  `shared` = tensors read by
         both (allocator bookkeeping for cross-stream use)."""
-        if not (self.two_streams and shared[0].is_cuda):
+        if not self._two(shared[0]):
             return f_i(), f_hv()
         main = torch.cuda.current_stream()
         side = getattr(self, "_side_stream", None)
@@ -132,7 +138,7 @@ class CIDNet(nn.Module, _HubMixin):
     def _lca_pair(self, I_blk, HV_blk, i, hv):
         if not (self.chain_lca_inputs and torch.is_grad_enabled() and (i.requires_grad or hv.requires_grad)):
             return self._par(lambda: I_blk(i, hv), lambda: HV_blk(hv, i), (i, hv))
-        two = self.two_streams and i.is_cuda
+        two = self._two(i)
         main = side = None
         if two:
             main = torch.cuda.current_stream()

@@ -269,8 +269,19 @@ def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None)
                _p(ws), ws.numel(), B, C, H, W, _stream())
 
 
+# Opt-in: run the dense 3x3 convs with K = 36 input channels on the BF16 matrix cores with exact three-way split operands
+# (csrc/conv3s.hip: results within fp32 rounding of the fp32-MFMA kernel, error against fp64 equal or smaller).  Off by
+# default: at M = K = 36 it measures 515-540 us against the fp32 kernel's 505-535 us at 8x36x400x600.
+CONV3_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_BF16X3", "0") == "1"}
+
+
 def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None):
     """y = conv3x3(x) (+ addend, in the kernel's epilogue; only for layers with more than 4 channels on both sides)"""
+    if CONV3_BF16X3["on"] and not replicate and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
+            and CONV3_BF16X3.get("filter", lambda *a: True)(M, K, H, W):
+        lib().call("cidnet_conv3x3_bf16x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), _p(addend), M * H * W, _p(y), M * H * W,
+                   B, M, K, H, W, _stream())
+        return
     if addend is None:
         lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
                    H, W, _stream())

@@ -177,6 +177,13 @@ void cidnet_debug_c3_flags(int flags);
 #endif
 int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
                    int replicate, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
+/* The same zero-pad convolution with its fp32 operands split into three bf16 values each and the six significant
+ * cross products run on the BF16 matrix cores (csrc/conv3s.hip): results within fp32 rounding of cidnet_conv3x3
+ * (products exact, fp32 accumulation, dropped terms <= 2^-25 relative), on a pipe the VALU does not contend for.
+ * R optional addend (batch stride r_bs).  _supported: shapes the kernel is instantiated for (K <= 40). */
+int cidnet_conv3x3_bf16x3_supported(int M, int K);
+int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, const float* R,
+                          long r_bs, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
 /* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
  * NormDownsample when its input also feeds a skip connection (net/CIDNet.py:80-81,85-86): the skip's gradient is
  * added in the epilogue instead of by a separate pass over the tensor.  Layers with <= 4 channels on a side

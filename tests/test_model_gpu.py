@@ -323,3 +323,59 @@ def test_cidnet_shape_sweep_vs_oracle(dev, shape, quantised):
         assert d <= tol, f"d{n} {shape}: max diff {d:.3e} > {tol:.3e}"
         n_checked += 1
     assert n_checked == 191 - 13
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_two_streams_bit_identical_to_single_stream(dev, storage):
+    """The two-branch schedule (cidnet.CIDNet._par / _lca_pair: I branch and HV branch on two streams) only reorders
+    independent kernels, so forward output and every parameter gradient must equal the single-stream run bit for bit, at
+    the full 8x400x600 size where the branches really overlap on the device -- in both storage modes."""
+    import hvi_cidnet_amd as P
+    m = P.CIDNet()
+    load(m, O.make_params(7))
+    m.to(dev)
+    x = O.synthetic_batch(91, (8, 3, 400, 600)).to(dev)
+
+    def run(two):
+        m.two_streams = two
+        for q in m.parameters():
+            q.grad = None
+        y = m(x)
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), torch.cat([q.grad.flatten() for q in m.parameters() if q.grad is not None]).clone()
+
+    P.set_storage_dtype(storage)
+    try:
+        y1, g1 = run(False)
+        for _ in range(2):
+            y2, g2 = run(True)
+            assert torch.equal(y1, y2)
+            assert torch.equal(g1, g2)
+    finally:
+        P.set_storage_dtype("f32")
+
+
+def test_cidnet_with_bf16x3_conv(dev):
+    """Opt-in split-product conv (ops.CONV3_BF16X3, csrc/conv3s.hip) inside the whole model: output within fp32 rounding of
+    the default path (2e-6 absolute on outputs in [0, 1]) and reproducible.  The mode serialises the two branches
+    (CIDNet._two): concurrently with the kernel's waves the stem conv was seen to drop products."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd import ops
+    m = P.CIDNet()
+    load(m, O.make_params(7))
+    m.to(dev)
+    m.two_streams = True
+    x = O.synthetic_batch(91, (8, 3, 400, 600)).to(dev)
+    old = dict(ops.CONV3_BF16X3)
+    try:
+        with torch.no_grad():
+            ops.CONV3_BF16X3["on"] = False
+            y32 = m(x)
+            ops.CONV3_BF16X3["on"] = True
+            ys = [m(x) for _ in range(3)]
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV3_BF16X3.update(old)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert (ys[0] - y32).abs().max().item() <= 2e-6
