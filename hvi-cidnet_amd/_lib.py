@@ -7,7 +7,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "cidnet_hip.h")
-LIB_PATH = os.path.join(_HERE, "libcidnet_hip.so")
+LIB_PATH = os.environ.get("CIDNET_LIB_PATH") or os.path.join(_HERE, "libcidnet_hip.so")   # override: A/B builds (dev)
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "void": None}
 _PROTO = re.compile(r"^\s*(int|long|void)\s+(cidnet_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)

@@ -22,7 +22,8 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # (more instructions in total, and past 256 VGPRs in the gate backward): the kernels there are VALU-issue-bound
 # iel.hip: same for the stencil stages of the tile-resident IEL kernel
 PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] if not os.environ.get("CIDNET_DW_SLP") else [],
-            "iel.hip": ["-fno-slp-vectorize"], "conv3s.hip": os.environ.get("CIDNET_C3S_FLAGS", "").split()}
+            "iel.hip": ["-fno-slp-vectorize"], "conv3s.hip": os.environ.get("CIDNET_C3S_FLAGS", "").split(),
+            "conv3_thin.hip": os.environ.get("CIDNET_THIN_FLAGS", "").split()}
 
 
 def _sources():

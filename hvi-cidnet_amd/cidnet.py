@@ -102,7 +102,7 @@ class CIDNet(nn.Module, _HubMixin):
         # The opt-in bf16x3 conv (ops.CONV3_BF16X3, csrc/conv3s.hip) must not share a CU with the other branch's kernels:
         # next to its waves the packed-fp32 FMAs of the stem conv drop single products (tools/c3s_batch_probe.py, DESIGN.md
         # section 4), so that mode runs the two branches one after the other.
-        return self.two_streams and t.is_cuda and not ops.CONV3_BF16X3["on"]
+        return self.two_streams and t.is_cuda and not (ops.CONV3_BF16X3["on"] and not ops.CONV3_BF16X3.get("allow_two_streams"))
 
     def _par(self, f_i, f_hv, shared):
         """Run f_i on the current stream and f_hv on a side stream, then join.  `shared` = tensors read by

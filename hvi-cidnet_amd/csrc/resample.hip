@@ -112,7 +112,7 @@ __global__ void bilinear_tab_kernel(int* __restrict__ idx, float* __restrict__ w
 // visits; a wave owns whole input rows (grid-stride over planes * Hi), so the y taps are wave-uniform (scalar
 // loads, uniform early exit) and a row's KX gathers hit neighbouring addresses across the wave.  KX bounds the
 // x taps of this launch (2 for the x0.5 adjoint, up to kTabK for x2); unused table slots hold (index 0, weight 0).
-template <int KX>
+template <int KX, int KY, int R>
 __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
                                                                 const int* __restrict__ yidx, const float* __restrict__ ywgt,
                                                                 const int* __restrict__ xidx, const float* __restrict__ xwgt,
@@ -126,22 +126,33 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const float* __r
     xo[k] = live ? xidx[xi * kTabK + k] : 0;
     xw[k] = live ? xwgt[xi * kTabK + k] : 0.f;
   }
+  // R rows per wave and trip, every tap unrolled (slots past a row's taps carry weight 0 and index 0): the R * KY * KX
+  // gathers of a trip are independent of one another, where a loop with an early exit paid the table load and the data
+  // load of each tap one after the other
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long stride = (long)gridDim.y * (kThreads / 64);
-  for (long r = (long)blockIdx.y * (kThreads / 64) + wave; r < nrows; r += stride) {
-    const int yi = (int)(r % Hi);
-    const float* g = dout + (r / Hi) * (long)Ho * Wo;
-    float s = 0.f;
-    for (int ky = 0; ky < kTabK; ++ky) {
-      const float wy = ywgt[yi * kTabK + ky];
-      if (wy == 0.f) break;                                  // taps are packed at the front of a table row
-      const float* row = g + (long)yidx[yi * kTabK + ky] * Wo;
-      float rs = 0.f;
+  const long stride = (long)gridDim.y * (kThreads / 64) * R;
+  for (long r0 = ((long)blockIdx.y * (kThreads / 64) + wave) * R; r0 < nrows; r0 += stride) {
+    float s[R];
 #pragma unroll
-      for (int k = 0; k < KX; ++k) rs += xw[k] * row[xo[k]];
-      s += wy * rs;
+    for (int j = 0; j < R; ++j) {
+      const long r = r0 + j < nrows ? r0 + j : nrows - 1;
+      const int yi = (int)(r % Hi);
+      const float* g = dout + (r / Hi) * (long)Ho * Wo;
+      float acc = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < KY; ++ky) {
+        const float wy = ywgt[yi * kTabK + ky];
+        const float* row = g + (long)yidx[yi * kTabK + ky] * Wo;
+        float rs = 0.f;
+#pragma unroll
+        for (int k = 0; k < KX; ++k) rs += xw[k] * row[xo[k]];
+        acc += wy * rs;
+      }
+      s[j] = acc;
     }
-    if (live) din[r * Wi + xi] = s;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (live && r0 + j < nrows) din[(r0 + j) * Wi + xi] = s[j];
   }
 }
 
@@ -211,22 +222,24 @@ int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(bilinear_tab_kernel, dim3((Wi + 255) / 256), dim3(256), 0, s, xidx, xwgt, Wi, Wo);
   CIDNET_LAUNCH_STATUS();
-  // x taps of one input column: outputs o with floor(o * s) in {i-1, i}, s = (in-1)/(out-1): at most floor(2/s) + 1
-  const double sx = Wo > 1 ? (double)(Wi - 1) / (double)(Wo - 1) : 0.0;
-  const int kx = sx > 0.0 ? (int)(2.0 / sx + 1e-3) + 1 : kTabK;
+  // taps of one input index: outputs o with floor(o * s) in {i-1, i}, s = (in-1)/(out-1): at most floor(2/s) + 1
+  const double sx = Wo > 1 ? (double)(Wi - 1) / (double)(Wo - 1) : 0.0, sy = Ho > 1 ? (double)(Hi - 1) / (double)(Ho - 1) : 0.0;
+  const int kx = sx > 0.0 ? (int)(2.0 / sx + 1e-3) + 1 : kTabK, ky = sy > 0.0 ? (int)(2.0 / sy + 1e-3) + 1 : kTabK;
+  const int k = kx > ky ? kx : ky;
   const long nrows = (long)B * C * Hi;
   const int gx = (Wi + 63) / 64;
-  long gy = (nrows + kThreads / 64 - 1) / (kThreads / 64);
+  const int R = k <= 2 ? 4 : 2;
+  long gy = (nrows + (kThreads / 64) * R - 1) / ((kThreads / 64) * R);
   const long cap = 16384 / gx > 0 ? 16384 / gx : 1;
   if (gy > cap) gy = cap;
   const dim3 grid((unsigned)gx, (unsigned)gy);
-  if (kx <= 2)
-    hipLaunchKernelGGL((bilinear_bwd_kernel<2>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho, Wo);
-  else if (kx <= 3)
-    hipLaunchKernelGGL((bilinear_bwd_kernel<3>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho, Wo);
-  else
-    hipLaunchKernelGGL((bilinear_bwd_kernel<kTabK>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho,
-                       Wo);
+#define CIDNET_BILINEAR_BWD(KK, RR) \
+  hipLaunchKernelGGL((bilinear_bwd_kernel<KK, KK, RR>), grid, dim3(kThreads), 0, s, dout, din, yidx, ywgt, xidx, xwgt, nrows, Hi, Wi, Ho, Wo)
+  if (k <= 2) CIDNET_BILINEAR_BWD(2, 4);
+  else if (k <= 3) CIDNET_BILINEAR_BWD(3, 2);
+  else if (k <= 5) CIDNET_BILINEAR_BWD(5, 2);
+  else CIDNET_BILINEAR_BWD(kTabK, 2);
+#undef CIDNET_BILINEAR_BWD
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -237,8 +237,25 @@ def _pe(t, off_elems=0):
     return _vp(t.data_ptr() + t.element_size() * int(off_elems))
 
 
+# 1x1 convs that are bound by the fp32 MFMA rate (many channels on the small planes of the two coarse levels) run on the BF16
+# matrix cores with exact three-way split operands (csrc/pws.hip).  "min_flops_per_byte": arithmetic intensity above which
+# a launch is taken to be MFMA-bound (2*M*K / (4*(M+K)) FLOP per byte of activation traffic).
+PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "0") == "1", "min_flops_per_byte": 17.0}
+
+
+def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
+    n = _raw("cidnet_pw_conv_bf16x3_ws_floats", B, M, K, int(w_bs != 0))
+    ws = _ws(n, x.device)
+    lib().call("cidnet_pw_conv_bf16x3", _po(x, x_off), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _po(y, y_off), y_bs,
+               _po(res, r_off) if res is not None else None, r_bs, _p(ws), ws.numel(), B, M, K, HW, _stream())
+
+
 def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
     """x / y may be bf16 tensors (offsets and strides in elements)"""
+    if PW_BF16X3["on"] and x.dtype == torch.float32 and y.dtype == torch.float32 \
+            and 2.0 * M * K / (4.0 * (M + K)) >= PW_BF16X3["min_flops_per_byte"] \
+            and _raw("cidnet_pw_conv_bf16x3_supported", M, K, HW):
+        return pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res, r_off, r_bs)
     lib().call("cidnet_pw_conv_t", _pe(x, x_off), _dt(x), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _pe(y, y_off), _dt(y), y_bs,
                _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, _stream())
 

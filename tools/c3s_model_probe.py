@@ -1,5 +1,5 @@
-"""Two-stream forward with the bf16x3 conv at the 400x600 sites: which placement of a device synchronisation (or which
-branch) makes the result reproducible?  (dev tool)"""
+"""Two-stream forward+backward with the bf16x3 conv enabled and the branch serialisation lifted: which tensors differ
+from the single-stream run?  (dev tool for the interference described in DESIGN.md section 4 (i))"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,51 +11,22 @@ m = P.CIDNet()
 p = O.make_params(7)
 m.load_state_dict({k: p[k] for k in m.state_dict().keys()}); m.to(dev)
 x = O.synthetic_batch(91, (8, 3, 400, 600)).to(dev)
-orig = ops.conv3x3
-mode = {"sync_before": False, "sync_after": False, "only_main": False, "only_side": False}
-main_id = torch.cuda.current_stream().cuda_stream
-def patched(xx, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None):
-    on_main = torch.cuda.current_stream().cuda_stream == main_id
-    use = H == 400 and not replicate and min(M, K) > 4
-    if mode["only_main"] and not on_main: use = False
-    if mode["only_side"] and on_main: use = False
-    ops.CONV3_BF16X3["on"] = use
-    if use and mode["sync_before"]: torch.cuda.synchronize()
-    orig(xx, w, y, B, M, K, H, W, w_ms, w_ks, flip=flip, replicate=replicate, addend=addend)
-    if use and mode["sync_after"]: torch.cuda.synchronize()
-    ops.CONV3_BF16X3["on"] = False
-ops.conv3x3 = patched
 caps = {}
-for name in ("IE_block0", "IE_block1", "HVE_block0", "HVE_block1", "I_LCA1", "HV_LCA1"):
-    getattr(m, name).register_forward_hook(lambda mod, i, o, name=name: caps.__setitem__(name, o))
-clones = {}
-m.IE_block0.register_forward_hook(lambda mod, i, o: clones.__setitem__("IE_block0", (o.clone(), i[0].clone(), i[0])))
-def run():
-    with torch.no_grad():
-        y = m(x)
+for name, mod in m.named_children():
+    mod.register_forward_hook(lambda mod, i, o, name=name: caps.__setitem__(name, o.detach() if torch.is_tensor(o) else None))
+ops.CONV3_BF16X3["on"] = True
+ops.CONV3_BF16X3["allow_two_streams"] = True
+def run(two):
+    m.two_streams = two
+    for q in m.parameters(): q.grad = None
+    y = m(x)
+    y.square().mean().backward()
     torch.cuda.synchronize()
-    return y
-m.two_streams = False
-ref = run()
-refcaps = dict(caps)
-print("single stream rerun diff", (run() - ref).abs().max().item())
-m.two_streams = True
-for cfg in ({"only_side": True},):
-    for k in mode: mode[k] = cfg.get(k, False)
-    for _ in range(3):
-        d = (run() - ref).abs().max().item()
-        print(cfg, "out %.2e" % d, {k: "%.1e" % (caps[k] - refcaps[k]).abs().max().item() for k in caps})
-        oc, ic, ii = clones["IE_block0"]
-        print("   clone-at-once vs ref %.1e; input clone vs input at end %.1e; recomputed now vs ref %.1e" % (
-            (oc - refcaps["IE_block0"]).abs().max().item(), (ic - ii).abs().max().item(),
-            (m.IE_block0(ii) - refcaps["IE_block0"]).abs().max().item()))
-        e = (caps["IE_block0"] - refcaps["IE_block0"]).abs() > 1e-4
-        idx = torch.nonzero(e)
-        print("   bad elements", idx.shape[0], "of", e.numel(), "per sample", e.sum((1, 2, 3)).tolist())
-        print("   per channel", e.sum((0, 2, 3)).tolist())
-        rows = e.sum((0, 1, 3)); cols = e.sum((0, 1, 2))
-        print("   rows with bad", torch.nonzero(rows).flatten().tolist()[:40], "n", (rows > 0).sum().item())
-        print("   cols with bad", torch.nonzero(cols).flatten().tolist()[:40], "n", (cols > 0).sum().item())
-        if idx.shape[0]:
-            b, c, yy, xx = idx[0].tolist()
-            print("   first", idx[0].tolist(), "got", caps["IE_block0"][b, c, yy, xx:xx+8].tolist(), "want", refcaps["IE_block0"][b, c, yy, xx:xx+8].tolist())
+    return y.detach().clone(), {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}, dict(caps)
+y1, g1, c1 = run(False)
+for t in range(3):
+    y2, g2, c2 = run(True)
+    badf = {k: int((c1[k] != c2[k]).sum()) for k in c1 if c1[k] is not None and not torch.equal(c1[k], c2[k])}
+    badg = {k: int((g1[k] != g2[k]).sum()) for k in g1 if not torch.equal(g1[k], g2[k])}
+    print("trial", t, "output differs in", int((y1 != y2).sum()), "elements; forward modules differing:", badf)
+    print("   gradients differing (first 12):", dict(list(badg.items())[:12]), "of", len(badg))
