@@ -99,10 +99,12 @@ class CIDNet(nn.Module, _HubMixin):
     two_streams = True
 
     def _two(self, t):
-        # The opt-in bf16x3 conv (ops.CONV3_BF16X3, csrc/conv3s.hip) must not share a CU with the other branch's kernels:
-        # next to its waves the packed-fp32 FMAs of the stem conv drop single products (tools/c3s_batch_probe.py, DESIGN.md
-        # section 4), so that mode runs the two branches one after the other.
-        return self.two_streams and t.is_cuda and not (ops.CONV3_BF16X3["on"] and not ops.CONV3_BF16X3.get("allow_two_streams"))
+        # The opt-in bf16x3 kernels (ops.CONV3_BF16X3 / ops.PW_BF16X3: csrc/conv3s.hip, csrc/pws.hip) must not share a CU with
+        # the other branch's kernels: next to bf16-MFMA waves the packed-fp32 FMAs of the stem conv were seen to drop single
+        # products (tools/c3s_batch_probe.py), so those modes run the two branches one after the other.
+        bf16_mfma = (ops.CONV3_BF16X3["on"] and not ops.CONV3_BF16X3.get("allow_two_streams")) or \
+            (ops.PW_BF16X3["on"] and not ops.PW_BF16X3.get("allow_two_streams"))
+        return self.two_streams and t.is_cuda and not bf16_mfma
 
     def _par(self, f_i, f_hv, shared):
         """Run f_i on the current stream and f_hv on a side stream, then join.  `shared` = tensors read by

@@ -237,10 +237,17 @@ def _pe(t, off_elems=0):
     return _vp(t.data_ptr() + t.element_size() * int(off_elems))
 
 
-# 1x1 convs that are bound by the fp32 MFMA rate (many channels on the small planes of the two coarse levels) run on the BF16
-# matrix cores with exact three-way split operands (csrc/pws.hip).  "min_flops_per_byte": arithmetic intensity above which
-# a launch is taken to be MFMA-bound (2*M*K / (4*(M+K)) FLOP per byte of activation traffic).
-PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "0") == "1", "min_flops_per_byte": 17.0}
+# Opt-in: 1x1 convs that are bound by the fp32 MFMA rate run on the BF16 matrix cores with exact three-way split operands
+# (csrc/pws.hip).  Taken for the launches where it measures faster than pw.hip (tools/micro_pws.py: reduction-heavy shapes,
+# K >= 1.9 M or K >= M >= 288 -- 1.2-1.9x; shapes with more output than input channels lose to the scalar stores and
+# the per-chunk re-split).  Off by default: +1.2 % on the step, and next to bf16-MFMA waves the packed-fp32 stem conv
+# needs a build without v_pk_* ops.
+PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "0") == "1",
+             "allow_two_streams": os.environ.get("CIDNET_BF16X3_TWO_STREAMS", "0") == "1"}
+
+
+def pw_bf16x3_wins(M, K):
+    return K >= 144 and (K >= 1.9 * M or (K >= M and M >= 288))
 
 
 def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
@@ -253,7 +260,7 @@ def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B
 def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
     """x / y may be bf16 tensors (offsets and strides in elements)"""
     if PW_BF16X3["on"] and x.dtype == torch.float32 and y.dtype == torch.float32 \
-            and 2.0 * M * K / (4.0 * (M + K)) >= PW_BF16X3["min_flops_per_byte"] \
+            and pw_bf16x3_wins(M, K) \
             and _raw("cidnet_pw_conv_bf16x3_supported", M, K, HW):
         return pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res, r_off, r_bs)
     lib().call("cidnet_pw_conv_t", _pe(x, x_off), _dt(x), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _pe(y, y_off), _dt(y), y_bs,

@@ -359,3 +359,45 @@ def test_conv3x3_bf16x3_split_products(dev, B, M, K, H, W, flip, add):
     e32 = (y32.cpu().double() - ref).abs().max().item()
     es = (ys.cpu().double() - ref).abs().max().item()
     assert es <= 1.5 * e32 + 1e-6 * ref.abs().max().item(), (es, e32)
+
+
+@pytest.mark.parametrize("B,M,K,HW,res,form", [
+    (2, 144, 766, 3750, False, "fwd"), (2, 766, 144, 3750, True, "fwd"), (3, 72, 382, 1501, True, "fwd"),
+    (2, 36, 36, 999, False, "fwd"), (1, 16, 32, 64, False, "fwd"), (2, 191, 72, 777, False, "dgrad"),
+    (2, 144, 144, 1000, True, "per_sample"), (1, 5, 7, 19, True, "fwd")])
+def test_pw_conv_bf16x3_split_products(dev, B, M, K, HW, res, form):
+    """csrc/pws.hip: the 1x1 conv on the BF16 matrix cores with exact three-way split operands against the fp64 product;
+    bar = 3x the fp32-MFMA kernel's own error + 2e-6 of the output scale (the matrix core's fp32 accumulation of six
+    products per term is a little looser than the fp32 MFMA at K = 766: 5e-6 against 1.3e-6).  Shapes: every block layout
+    (1, 2, 4 waves along M; 1-3 channel tiles per wave; several channel chunks), ragged pixel / channel / K tails, the
+    data-gradient weight strides and per-sample weights (attention fold)."""
+    from hvi_cidnet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M * 7 + K)
+    x = torch.randn(B, K, HW, device=dev, generator=g)
+    r = torch.randn(B, M, HW, device=dev, generator=g) if res else None
+    if form == "dgrad":                                     # weight stored (K, M): A[m][k] = w[k][m]
+        w = torch.randn(K, M, device=dev, generator=g) / K ** 0.5
+        w_bs, w_ms, w_ks = 0, 1, M
+        a = w.t().double().cpu().expand(B, M, K)
+    elif form == "per_sample":
+        w = torch.randn(B, M, K, device=dev, generator=g) / K ** 0.5
+        w_bs, w_ms, w_ks = M * K, K, 1
+        a = w.double().cpu()
+    else:
+        w = torch.randn(M, K, device=dev, generator=g) / K ** 0.5
+        w_bs, w_ms, w_ks = 0, K, 1
+        a = w.double().cpu().expand(B, M, K)
+    ref = torch.bmm(a, x.double().cpu())
+    if res:
+        ref = ref + r.double().cpu()
+    y32, ys = torch.empty(B, M, HW, device=dev), torch.full((B, M, HW), float("nan"), device=dev)
+    old = dict(ops.PW_BF16X3)
+    try:
+        ops.PW_BF16X3["on"] = False
+        ops.pw_conv(x, 0, K * HW, w, 0, w_bs, w_ms, w_ks, y32, 0, M * HW, B, M, K, HW, res=r, r_off=0, r_bs=M * HW)
+    finally:
+        ops.PW_BF16X3.update(old)
+    ops.pw_conv_bf16x3(x, 0, K * HW, w, 0, w_bs, w_ms, w_ks, ys, 0, M * HW, B, M, K, HW, res=r, r_off=0, r_bs=M * HW)
+    e32 = (y32.cpu().double() - ref).abs().max().item()
+    es = (ys.cpu().double() - ref).abs().max().item()
+    assert es <= 3 * e32 + 2e-6 * ref.abs().max().item(), (es, e32)
