@@ -503,7 +503,7 @@ struct C3WgArgs {
   int M, N, H, W;
   int replicate;
   int rr;           // rows per chunk
-  int nseg4;        // ceil(nseg / 4): x-segment groups
+  int ncol, nitems; // 32-pixel column tiles per row; work items = ncol * row chunks (a wave owns one item)
   int nfull, ngrp;  // 16-wide n tiles, 4-wide groups of the input-channel remainder
   int nby;          // (m block, n block) pairs per pixel chunk in this launch
   int nchunk;       // pixel chunks per sample
@@ -587,11 +587,14 @@ __global__ __launch_bounds__(kThreads) void conv3_wgrad_kernel(C3WgArgs a) {
   const int nny = NLEFT ? a.ngrp : a.nfull;       // n blocks of this launch
   const int mb = by / nny, nt = by - mb * nny;
   const int m0 = mb * MB, n0 = NLEFT ? a.nfull * 16 + nt * 4 : nt * 16;
-  const int segg = chunk % a.nseg4, rchunk = chunk / a.nseg4;
+  // work items (column tile, row chunk) are dealt to the waves of consecutive blocks in one flat sequence, so a plane whose
+  // width is not a multiple of 128 leaves no wave idle (150 px = 5 column tiles: 8 wave slots per row chunk before)
+  const int item = chunk * 4 + wave;
+  const bool seg_ok = item < a.nitems;
+  const int col = seg_ok ? item % a.ncol : 0, rchunk = seg_ok ? item / a.ncol : 0;
   const int H = a.H, W = a.W;
   const long HW = (long)H * W;
-  const int xs = ((segg * 4 + wave) * 32) + 8 * j;         // this lane's first pixel of the segment
-  const bool seg_ok = (segg * 4 + wave) * 32 < W;
+  const int xs = col * 32 + 8 * j;                         // this lane's first pixel of the segment
   // the lane that crosses the right border is pulled back to W-8 and its first `dup` pixels (owned by its left
   // neighbour) are masked out of the A operand; lanes entirely past the border mask everything (W >= 8)
   const int xq = min(xs, W - 8), dup = xs - xq;
@@ -802,13 +805,15 @@ inline WgSplit wg_split(int M, int N) {
 // a grid just above a multiple of 512 pays a whole extra round for a few blocks.  Pick the cheapest row count >= 8.
 inline int wg_rows(int B, int M, int N, int H, int W) {
   const WgSplit w = wg_split(M, N);
-  const long per_rc = (long)(((W + 31) / 32 + 3) / 4) * w.nmb * w.nfull * B;     // blocks of the main launch per row chunk
+  const int ncol = (W + 31) / 32;
+  const long per_chunk = (long)w.nmb * w.nfull * B;                               // blocks of the main launch per pixel chunk
   int best_rr = H;
   long best_cost = -1;
   for (int nrc = 1; nrc <= H; ++nrc) {
     const int rr = (H + nrc - 1) / nrc;
     if (rr < 8 && nrc > 1) break;
-    const long rounds = (per_rc * ((H + rr - 1) / rr) + 511) / 512;
+    const long chunks = ((long)ncol * ((H + rr - 1) / rr) + 3) / 4;
+    const long rounds = (per_chunk * chunks + 511) / 512;
     const long cost = rounds * (rr + 6);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rr = rr; }
   }
@@ -913,7 +918,7 @@ int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w
 long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W) {
   if (c3_thin_applies(M, N) && !(g_c3_dbg & 8)) return (long)B * c3_thin_wgrad_chunks(H, W) * M * N * 9;
   const int rr = wg_rows(B, M, N, H, W);
-  const long chunks = (long)(((W + 31) / 32 + 3) / 4) * ((H + rr - 1) / rr);
+  const long chunks = ((long)((W + 31) / 32) * ((H + rr - 1) / rr) + 3) / 4;
   return (long)B * chunks * M * N * 9;
 }
 
@@ -939,8 +944,9 @@ int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs,
   C3WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.X = X; a.x_bs = x_bs; a.slabs = ws; a.M = M; a.N = N; a.H = H; a.W = W;
   a.replicate = replicate; a.rr = wg_rows(B, M, N, H, W);
-  a.nseg4 = ((W + 31) / 32 + 3) / 4;
-  const int chunks = a.nseg4 * ((H + a.rr - 1) / a.rr);
+  a.ncol = (W + 31) / 32;
+  a.nitems = a.ncol * ((H + a.rr - 1) / a.rr);
+  const int chunks = (a.nitems + 3) / 4;
   const WgSplit sp = wg_split(M, N);
   const int MT = sp.MT, LEFT = sp.LEFT, nmb = sp.nmb, nfull = sp.nfull, ngrp = sp.ngrp;
   hipStream_t s = (hipStream_t)stream;
