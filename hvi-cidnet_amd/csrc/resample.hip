@@ -156,6 +156,76 @@ __global__ __launch_bounds__(kThreads) void bilinear_bwd_kernel(const float* __r
   }
 }
 
+// The x2 adjoint (NormUpsample backward: din is half the size of dout) reads 4x more than it writes and every output
+// row feeds two input rows, every output column two input columns: gathered from global memory that is ~25 dword loads per
+// result through the L1 (245 us at 8x36x400x600 -> 200x300, 1.4 TB/s).  Here a block stages the contiguous band of dout
+// rows that its TR input rows need into LDS with coalesced 16-byte loads (each dout element is read from memory exactly
+// once per band, bands overlap by ~3 rows) and gathers from LDS.  A thread owns up to NC fixed columns (x taps in
+// registers); the y taps of a row are block-uniform.  Same taps, same summation order as bilinear_bwd_kernel.
+template <int KX, int KY, int NC, int TR>
+__global__ __launch_bounds__(kThreads) void bilinear_bwd_band_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                     const int* __restrict__ yidx, const float* __restrict__ ywgt,
+                                                                     const int* __restrict__ xidx, const float* __restrict__ xwgt,
+                                                                     int Hi, int Wi, int Ho, int Wo, int tiles_per_plane, int max_rows) {
+  extern __shared__ float band[];                 // [rows][Wo]
+  const long pl = blockIdx.x / tiles_per_plane;
+  const int r0 = (blockIdx.x - (int)pl * tiles_per_plane) * TR, r1 = min(r0 + TR, Hi);
+  int xo[NC][KX];
+  float xw[NC][KX];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int xi = threadIdx.x + c * kThreads;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      xo[c][k] = xi < Wi ? xidx[xi * kTabK + k] : 0;
+      xw[c][k] = xi < Wi ? xwgt[xi * kTabK + k] : 0.f;
+    }
+  }
+  // band of output rows [ylo, yhi]: taps ascend within a row (packed at the front of its table row) and from row to row,
+  // so the band runs from the first tap of the first row that has any to the last tap of the last row that has any (a
+  // row has none when the map skips inputs)
+  int ylo = 0, yhi = -1;
+  for (int yi = r0; yi < r1; ++yi)
+    if (ywgt[yi * kTabK] != 0.f) { ylo = yidx[yi * kTabK]; break; }
+  for (int yi = r1 - 1; yi >= r0 && yhi < 0; --yi)
+    for (int k = KY - 1; k >= 0; --k)
+      if (ywgt[yi * kTabK + k] != 0.f) { yhi = yidx[yi * kTabK + k]; break; }
+  if (yhi < ylo) yhi = ylo;
+  const int nrow = min(yhi - ylo + 1, max_rows);
+  const float* src = dout + (pl * Ho + ylo) * (long)Wo;
+  const int n = nrow * Wo, n4 = n >> 2;
+  for (int i = threadIdx.x; i < n4; i += kThreads) {
+    const f32x4 v = load4u(src + 4 * i);
+    band[4 * i] = v[0]; band[4 * i + 1] = v[1]; band[4 * i + 2] = v[2]; band[4 * i + 3] = v[3];
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += kThreads) band[i] = src[i];
+  __syncthreads();
+  for (int yi = r0; yi < r1; ++yi) {
+    float s[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KY; ++ky) {
+      const float wy = ywgt[yi * kTabK + ky];
+      // rows past the band can only belong to zero-weight slots (index 0): keep the address inside the band
+      const int rr = min(max(yidx[yi * kTabK + ky] - ylo, 0), nrow - 1);
+      const float* row = band + rr * Wo;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float rs = 0.f;
+#pragma unroll
+        for (int k = 0; k < KX; ++k) rs += xw[c][k] * row[xo[c][k]];
+        s[c] += wy * rs;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int xi = threadIdx.x + c * kThreads;
+      if (xi < Wi) din[(pl * Hi + yi) * (long)Wi + xi] = s[c];
+    }
+  }
+}
+
 // y = a + b (residual sums that no GEMM epilogue absorbs)
 __global__ __launch_bounds__(kThreads) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ y, long n) {
@@ -226,6 +296,29 @@ int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats
   const double sx = Wo > 1 ? (double)(Wi - 1) / (double)(Wo - 1) : 0.0, sy = Ho > 1 ? (double)(Hi - 1) / (double)(Ho - 1) : 0.0;
   const int kx = sx > 0.0 ? (int)(2.0 / sx + 1e-3) + 1 : kTabK, ky = sy > 0.0 ? (int)(2.0 / sy + 1e-3) + 1 : kTabK;
   const int k = kx > ky ? kx : ky;
+  // the two resampling adjoints of the model (x2 and x0.5, up to 5 resp. 2 taps per axis): band kernel when the band of
+  // output rows that TR input rows need fits the LDS budget
+  if ((k <= 2 || (k > 3 && k <= 5)) && Wi <= 3 * kThreads && sy > 0.0) {
+    const int TR = k <= 2 ? 16 : 8;
+    const int max_rows = (int)((TR + 1) / sy) + 4;             // outputs per input row = 1 / sy
+    const size_t lds = (size_t)max_rows * Wo * sizeof(float);
+    if (lds <= 64 * 1024) {
+      const int tiles = (Hi + TR - 1) / TR;
+      const dim3 grid((unsigned)((long)B * C * tiles));
+      const int nc = (Wi + kThreads - 1) / kThreads;
+#define CIDNET_BAND(KK, NC, TRR)                                                                                           \
+  hipLaunchKernelGGL((bilinear_bwd_band_kernel<KK, KK, NC, TRR>), grid, dim3(kThreads), lds, s, dout, din, yidx, ywgt, xidx, xwgt, Hi, \
+                     Wi, Ho, Wo, tiles, max_rows)
+      if (k <= 2) {
+        if (nc == 1) CIDNET_BAND(2, 1, 16); else if (nc == 2) CIDNET_BAND(2, 2, 16); else CIDNET_BAND(2, 3, 16);
+      } else {
+        if (nc == 1) CIDNET_BAND(5, 1, 8); else if (nc == 2) CIDNET_BAND(5, 2, 8); else CIDNET_BAND(5, 3, 8);
+      }
+#undef CIDNET_BAND
+      CIDNET_LAUNCH_STATUS();
+      return CIDNET_OK;
+    }
+  }
   const long nrows = (long)B * C * Hi;
   const int gx = (Wi + 63) / 64;
   const int R = k <= 2 ? 4 : 2;
