@@ -253,11 +253,11 @@ def main():
     # has to hipMalloc costs 60-80 ms on the host.  Run un-synchronised steps until a step adds no device segment.
     segs = lambda: torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     quiet = 0
-    for _ in range(12):
+    for _ in range(12 if world == 1 else 8):           # every step holds a collective: all ranks must run the same number
         before = segs()
         trainer.step(x, gt)
         quiet = quiet + 1 if segs() == before else 0
-        if quiet >= 3:
+        if quiet >= 3 and world == 1:
             break
     sync()
     for _ in range(max(a.warmup, 1)):
