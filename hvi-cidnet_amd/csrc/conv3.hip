@@ -803,6 +803,9 @@ inline WgSplit wg_split(int M, int N) {
 // Rows per pixel chunk.  256 CUs hold 512 of these blocks at a time (2 waves per SIMD), and a block's run time is
 // (rows + ~6 rows' worth of prologue / 9-round epilogue), so the launch costs about ceil(blocks / 512) * (rows + 6):
 // a grid just above a multiple of 512 pays a whole extra round for a few blocks.  Pick the cheapest row count >= 8.
+#ifndef C3_WG_OVH
+#define C3_WG_OVH 6      // fixed cost of a block (window prologue, LDS sum, slab store) in units of one row's burst
+#endif
 inline int wg_rows(int B, int M, int N, int H, int W) {
   const WgSplit w = wg_split(M, N);
   const int ncol = (W + 31) / 32;
@@ -814,7 +817,7 @@ inline int wg_rows(int B, int M, int N, int H, int W) {
     if (rr < 8 && nrc > 1) break;
     const long chunks = ((long)ncol * ((H + rr - 1) / rr) + 3) / 4;
     const long rounds = (per_chunk * chunks + 511) / 512;
-    const long cost = rounds * (rr + 6);
+    const long cost = rounds * (rr + C3_WG_OVH);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rr = rr; }
   }
   return best_rr;
