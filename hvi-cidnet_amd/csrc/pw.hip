@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 // Requires HW % 4 == 0 (streaming addressing, see pw_conv_kernel) -- the ragged tail tile of other
 // planes goes through pw_conv_kernel<.., TAIL = true>.
 template <int MT, int EPI, int KS, class DT>
-__global__ __launch_bounds__(kThreads, (EPI == 2 && !(MT <= 3 && KS == 9) ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
+__global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT <= 3 && KS == 9)) || MT >= 5 ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
   constexpr int MB = 16 * MT;
   // prefetch distance in k-steps: a whole 9-step tile ahead (~4600 MFMA cycles per wave, and the
   // co-resident wave doubles it) -- HBM latency under load is several thousand cycles
@@ -448,15 +448,18 @@ int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
 }
 
 // -> true if a register-resident instantiation exists for (MT, K); launches it.  Register budget
-// (2 waves/SIMD): MT <= 4 with 9 k-steps, MT <= 3 with 18 or 24.
+// (2 waves/SIMD): MT <= 4 with 9 k-steps, MT <= 3 with 18 or 24; MT = 5 (65..80 output channels in ONE block, one block
+// per CU) with 9 or 18 k-steps.
 template <int MT, int EPI, class DT>
 bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
   const int ks = (a.K + 3) / 4;
-  if constexpr (MT <= 4) {
+  if constexpr (MT <= 5) {
     if (ks <= 9) { *rc = launch_pw_rega<MT, EPI, 9, DT>(a, B, nstream, s); return true; }
   }
-  if constexpr (MT <= 3) {
+  if constexpr (MT <= 3 || MT == 5) {
     if (ks <= 18) { *rc = launch_pw_rega<MT, EPI, 18, DT>(a, B, nstream, s); return true; }
+  }
+  if constexpr (MT <= 3) {
     if (ks <= 24) { *rc = launch_pw_rega<MT, EPI, 24, DT>(a, B, nstream, s); return true; }
   }
   return false;
@@ -668,6 +671,10 @@ int dispatch_pw_dt(PwArgs a, int epi, int B, hipStream_t s) {
       if (pad <= T + 1 && pad < best_pad) { best = mt; best_pad = pad; }
     }
     MT = best;
+    // 65..80 output channels (the 36 -> 72 kv conv, the 72 x 72 attention maps): all five tiles in one block at one block per
+    // CU, so the input is read once instead of twice (3 + 2 tiles): 70 -> 60 us and 120 -> 85 us at 200x300.  Six tiles
+    // (95 / 190 channels) and four tiles at 18 k-steps spill and measured slower.
+    if (T == 5 && ks <= 18) MT = 5;
     if (g_pw_force_mt >= 1 && g_pw_force_mt <= mtmax) MT = g_pw_force_mt;
   } else {
     int nblk = (T + 5) / 6;
