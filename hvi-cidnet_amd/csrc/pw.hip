@@ -311,9 +311,14 @@ __global__ __launch_bounds__(kThreads) void pw_conv_kernel(PwArgs a) {
 // block walks `tpb` pixel tiles and prefetches the next tile's first k-steps before it stores.
 // Requires HW % 4 == 0 (streaming addressing, see pw_conv_kernel) -- the ragged tail tile of other
 // planes goes through pw_conv_kernel<.., TAIL = true>.
-template <int MT, int EPI, int KS, class DT>
-__global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT <= 3 && KS == 9)) || MT >= 5 ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
-  constexpr int MB = 16 * MT;
+// LEFT = 1: the block's last 1..4 output channels form a 4-row group computed with v_mfma_f32_4x4x1_16b_f32 instead of a
+// padded 16-row tile (M = 36 = 2 tiles + 1 group: 288 instead of 384 MFMA cycles per k-step; same idiom as conv3.hip):
+// the instruction's 16 blocks are (k-slot j) x (4 lanes), lane (c, j) feeds its own pixel values as B and
+// W[16 MT + (c & 3)][4 ks + j] as A, so a 16-lane group accumulates the share of ITS k-slot; the four shares are added
+// across the groups once per tile and lane (c, j) stores row 16 MT + j.
+template <int MT, int EPI, int KS, class DT, int LEFT = 0>
+__global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT + LEFT <= 3 && KS == 9)) || MT >= 5 ? 1 : 2)) void pw_conv_rega_kernel(PwArgs a) {
+  constexpr int MB = 16 * MT + 4 * LEFT;
   // prefetch distance in k-steps: a whole 9-step tile ahead (~4600 MFMA cycles per wave, and the
   // co-resident wave doubles it) -- HBM latency under load is several thousand cycles
   constexpr int D = KS == 24 ? 8 : 9;
@@ -350,10 +355,13 @@ __global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT <= 3 && KS == 9)) || M
   }
   __syncthreads();
   float areg[KS][MT];
+  float al[LEFT ? KS : 1];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) areg[ks][mt] = Ws[(mt * 16 + c) * LDW + 4 * ks + j];
+    if (LEFT) al[ks] = Ws[(MT * 16 + (c & 3)) * LDW + 4 * ks + j];
+  }
 
   auto xrow = [&](long tile, int ks) -> long {
     const long p0 = tile * 256 + wave * 64 + 4 * c;
@@ -368,10 +376,13 @@ __global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT <= 3 && KS == 9)) || M
   for (long tile = tile_beg; tile < tile_end; ++tile) {
     const long p0 = tile * 256 + wave * 64 + 4 * c;
     f32x4 acc[MT][4];
+    f32x4 accl[4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) accl[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const f32x4 xc = ring[ks % D];
@@ -383,6 +394,21 @@ __global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT <= 3 && KS == 9)) || M
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks][mt], xc[e], acc[mt][e], 0, 0, 0);
+      if (LEFT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accl[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(al[ks], xc[e], accl[e], 0, 0, 0);
+      }
+    }
+    if (LEFT) {                                      // add the four k-slot shares (all lanes take part)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = accl[e][q];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          accl[e][q] = v;
+        }
     }
 
     if (p0 >= HW) continue;
@@ -400,36 +426,45 @@ __global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT <= 3 && KS == 9)) || M
 #pragma unroll
       for (int e = 0; e < 4; ++e) tap[e] = up_tap(p0 + e, a.W, a.zh, a.zw);
     }
+    auto emit = [&](int m, f32x4 v) __attribute__((always_inline)) {
+      if (EPI == 1) v += load4u(a.R + (long)b * a.r_bs + (long)m * HW + p0);
+      if (EPI == 2) {
+        const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const UpTap& t = tap[e];
+          const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
+          const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
+          v[e] += (1.f - t.ly) * top + t.ly * bot;
+        }
+        if (a.Ypre) store4u(a.Ypre + (long)b * a.y_bs + (long)m * HW + p0, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+      }
+      st4t(a.Y, (long)b * a.y_bs + (long)m * HW + p0, ydt, v);
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int m = m0 + mt * 16 + j * 4 + reg;
         if (m >= a.M) continue;
-        f32x4 v = {acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
-        if (EPI == 1) v += load4u(a.R + (long)b * a.r_bs + (long)m * HW + p0);
-        if (EPI == 2) {
-          const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const UpTap& t = tap[e];
-            const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
-            const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
-            v[e] += (1.f - t.ly) * top + t.ly * bot;
-          }
-          if (a.Ypre) store4u(a.Ypre + (long)b * a.y_bs + (long)m * HW + p0, v);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
-        }
-        st4t(a.Y, (long)b * a.y_bs + (long)m * HW + p0, ydt, v);
+        emit(m, f32x4{acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]});
+      }
+    }
+    if (LEFT) {                                      // lane (c, j) stores row 16 MT + j of the 4-row group
+      const int m = m0 + MT * 16 + j;
+      if (m < a.M) {
+        auto pick = [](f32x4 v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); };
+        emit(m, f32x4{pick(accl[0], j), pick(accl[1], j), pick(accl[2], j), pick(accl[3], j)});
       }
     }
   }
 }
 
-template <int MT, int EPI, int KS, class DT>
+template <int MT, int EPI, int KS, class DT, int LEFT = 0>
 int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
-  constexpr int MB = 16 * MT;
+  constexpr int MB = 16 * MT + 4 * LEFT;
   const long mblocks = (a.M + MB - 1) / MB;
   // 512 blocks are resident (two per CU).  Store-heavy, bandwidth-bound layers (M >= 2K, below ~25 FLOP/B: e.g. the
   // 36 -> 190 project_in at 200x300) run 15 % faster as about two rounds of shorter blocks; read-heavy and MFMA-bound
@@ -442,7 +477,7 @@ int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
   a.tile0 = 0;
   a.ntile_lim = (int)nstream;
   dim3 grid((unsigned)((nstream + tpb - 1) / tpb), (unsigned)mblocks, (unsigned)B);
-  hipLaunchKernelGGL((pw_conv_rega_kernel<MT, EPI, KS, DT>), grid, dim3(kThreads), 0, s, a);
+  hipLaunchKernelGGL((pw_conv_rega_kernel<MT, EPI, KS, DT, LEFT>), grid, dim3(kThreads), 0, s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -453,6 +488,17 @@ int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
 template <int MT, int EPI, class DT>
 bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
   const int ks = (a.K + 3) / 4;
+  // all output channels in one block and the last tile holds 1..4 of them (M = 36): 4-row group instead of a padded tile
+  if constexpr (MT >= 2 && MT <= 4) {
+    const int rem = a.M - 16 * (MT - 1);
+    if (a.M <= 16 * MT && rem >= 1 && rem <= 4 && !(a.dbg & 32)) {
+      if (ks <= 9) { *rc = launch_pw_rega<MT - 1, EPI, 9, DT, 1>(a, B, nstream, s); return true; }
+      if constexpr (MT <= 3) {
+        if (ks <= 18) { *rc = launch_pw_rega<MT - 1, EPI, 18, DT, 1>(a, B, nstream, s); return true; }
+        if (ks <= 24) { *rc = launch_pw_rega<MT - 1, EPI, 24, DT, 1>(a, B, nstream, s); return true; }
+      }
+    }
+  }
   if constexpr (MT <= 5) {
     if (ks <= 9) { *rc = launch_pw_rega<MT, EPI, 9, DT>(a, B, nstream, s); return true; }
   }
