@@ -419,24 +419,40 @@ __global__ __launch_bounds__(kThreads, ((EPI == 2 && !(MT + LEFT <= 3 && KS == 9
         for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[mt][e]));
       continue;
     }
-    UpTap tap[4];
-    float slope = 0.f;
-    if (EPI == 2) {
+    // x2 bilinear epilogue.  The lane's four pixels lie in one output row (W % 4 == 0, checked by the launcher), so they
+    // share the two source rows and draw on at most four consecutive source columns: per output channel TWO 16-byte loads
+    // of the low-resolution plane and a 4 x 4 horizontal weight matrix, instead of sixteen 4-byte gathers (the gathers
+    // made this kernel run at 2.6 TB/s; 576 of them per wave and tile against 9 operand loads).
+    float slope = 0.f, ly = 0.f, cw[4][4];
+    long zo0 = 0, zo1 = 0;
+    if (EPI == 2) {                                  // try_rega sends planes with W % 4 != 0 (150-pixel rows) to pw_conv_kernel
       slope = a.slope[0];
+      const int W = a.W, zh = a.zh, zw = a.zw, H = 2 * zh;
+      const int y = (int)(p0 / W), x = (int)(p0 - (long)y * W);
+      const float sh = (H > 1) ? (float)(zh - 1) / (float)(H - 1) : 0.f;
+      const float sw = (W > 1) ? (float)(zw - 1) / (float)(W - 1) : 0.f;
+      const float fy = sh * (float)y;
+      const int y0 = (int)fy, y1 = y0 + (y0 < zh - 1 ? 1 : 0);
+      ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f);
+      const int start = min((int)(sw * (float)x), zw - 4);
+      zo0 = (long)y0 * zw + start; zo1 = (long)y1 * zw + start;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tap[e] = up_tap(p0 + e, a.W, a.zh, a.zw);
+      for (int e = 0; e < 4; ++e) {
+        const float fx = sw * (float)(x + e);
+        const int x0 = (int)fx, x1 = x0 + (x0 < zw - 1 ? 1 : 0);
+        const float lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cw[e][q] = (x0 - start == q ? 1.f - lx : 0.f) + (x1 - start == q ? lx : 0.f);
+      }
     }
     auto emit = [&](int m, f32x4 v) __attribute__((always_inline)) {
       if (EPI == 1) v += load4u(a.R + (long)b * a.r_bs + (long)m * HW + p0);
       if (EPI == 2) {
         const float* z = a.Z + ((long)b * a.M + m) * ((long)a.zh * a.zw);
+        const f32x4 zt = load4u(z + zo0), zb = load4u(z + zo1);
+        const f32x4 zl = zt + ly * (zb - zt);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const UpTap& t = tap[e];
-          const float top = (1.f - t.lx) * z[t.o00] + t.lx * z[t.o01];
-          const float bot = (1.f - t.lx) * z[t.o10] + t.lx * z[t.o11];
-          v[e] += (1.f - t.ly) * top + t.ly * bot;
-        }
+        for (int e = 0; e < 4; ++e) v[e] += (cw[e][0] * zl[0] + cw[e][1] * zl[1]) + (cw[e][2] * zl[2] + cw[e][3] * zl[3]);
         if (a.Ypre) store4u(a.Ypre + (long)b * a.y_bs + (long)m * HW + p0, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
@@ -488,6 +504,7 @@ int launch_pw_rega(PwArgs a, int B, long nstream, hipStream_t s) {
 template <int MT, int EPI, class DT>
 bool try_rega(const PwArgs& a, int B, long nstream, hipStream_t s, int* rc) {
   const int ks = (a.K + 3) / 4;
+  if (EPI == 2 && ((a.W & 3) != 0 || a.zw < 4)) return false;   // its x2 epilogue wants a lane's four pixels in one row
   // all output channels in one block and the last tile holds 1..4 of them (M = 36): 4-row group instead of a padded tile
   if constexpr (MT >= 2 && MT <= 4) {
     const int rem = a.M - 16 * (MT - 1);
