@@ -414,8 +414,10 @@ int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, flo
   CIDNET_CHECK_ARG(x && weight && bias && y && B > 0 && C > 0 && HW > 0);
   CIDNET_CHECK_ARG((mean == nullptr) == (rstd == nullptr));
   hipStream_t s = (hipStream_t)stream;
-  if (C == 36 && HW % 4 == 0)
-    hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 4>), dim3(grid_for((long)B * HW / 4)), dim3(kThreads), 0, s, x, weight, bias, y,
+  // C = 36: one pixel per lane (36 registers of column) -- 4 pixels per lane left under two waves per SIMD for the whole
+  // launch at 200x300, i.e. one read burst followed by one write burst: 26.8 -> 23.7 us (tools/micro_ln.py)
+  if (C == 36)
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
                        mean, rstd, B, HW, eps);
   else if (C == 72 && HW % 2 == 0)
     hipLaunchKernelGGL((ln_fwd_reg_kernel<72, 2>), dim3(grid_for((long)B * HW / 2)), dim3(kThreads), 0, s, x, weight, bias, y,
