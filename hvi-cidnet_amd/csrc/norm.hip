@@ -451,13 +451,16 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
   hipStream_t s = (hipStream_t)stream;
   if (gx && ((C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0) || (C == 144 && (long)B * HW <= (1L << 18))) &&
       ws_floats >= 2L * C * kFusedBlocks && !g_ln_unfused) {
-    const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 2 : (long)B * HW * 8);
+    const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 2 : (HW % 2 == 0 ? (long)B * HW * 4 : (long)B * HW * 8));
     const int nblk = (int)((lanes + kThreads - 1) / kThreads < kFusedBlocks ? (lanes + kThreads - 1) / kThreads : kFusedBlocks);
     if (C == 36)
       hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 4, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
                          ws, B, HW);
     else if (C == 72)
       hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
+                         ws, B, HW);
+    else if (HW % 2 == 0)                                     // two pixels per lane group: 38.5 -> 30.4 us at 8x144x50x75
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
                          ws, B, HW);
     else
       hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 1, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
