@@ -22,7 +22,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # (more instructions in total, and past 256 VGPRs in the gate backward): the kernels there are VALU-issue-bound
 # iel.hip: same for the stencil stages of the tile-resident IEL kernel
 PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] if not os.environ.get("CIDNET_DW_SLP") else [],
-            "iel.hip": ["-fno-slp-vectorize"], "conv3s.hip": os.environ.get("CIDNET_C3S_FLAGS", "").split(),
+            "iel.hip": ["-fno-slp-vectorize"],
+            # split-product kernels: no packed-fp32 / SDWA instructions beside LDS-fed bf16 MFMAs
+            "conv3x.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sdwa-peephole=0", *os.environ.get("CIDNET_C3X_FLAGS", "").split()],
             "conv3_thin.hip": os.environ.get("CIDNET_THIN_FLAGS", "").split()}
 
 

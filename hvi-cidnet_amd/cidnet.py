@@ -1,5 +1,7 @@
 """`CIDNet`: drop-in for the reference's net/CIDNet.py module (same constructor, attribute `trans`,
 method `HVIT`, 191 state_dict keys) running entirely on the hand-written gfx950 kernels."""
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -13,6 +15,20 @@ try:  # the reference mixes this in for from_pretrained/save_pretrained (net/CID
 except Exception:  # pragma: no cover - hub client not installed
     class _HubMixin:  # type: ignore
         pass
+
+
+# Per-module runtime objects (side stream, back-pressure events) live OUTSIDE the module: HIP streams and events cannot be
+# pickled or deep-copied, and a model must stay copy.deepcopy()-able (EMA copies) and torch.save()-able after its first
+# forward.  Keyed weakly by the module; a copy starts with fresh state on whatever device it runs on.
+_RUNTIME = weakref.WeakKeyDictionary()
+
+
+def _runtime(module, device):
+    st = _RUNTIME.get(module)
+    if st is None or st["device"] != device:
+        st = {"device": device, "side": None, "events": []}
+        _RUNTIME[module] = st
+    return st
 
 
 class _RepConv(nn.Sequential):
@@ -106,16 +122,25 @@ class CIDNet(nn.Module, _HubMixin):
             (ops.PW_BF16X3["on"] and not ops.PW_BF16X3.get("allow_two_streams"))
         return self.two_streams and t.is_cuda and not bf16_mfma
 
+    def _side(self, device):
+        st = _runtime(self, device)
+        if st["side"] is None:
+            st["side"] = torch.cuda.Stream(device=device)
+        return st["side"]
+
+    @property
+    def _side_stream(self):
+        """the HV branch's stream once a two-stream forward has run on the current device (None before)"""
+        st = _RUNTIME.get(self)
+        return st["side"] if st is not None else None
+
     def _par(self, f_i, f_hv, shared):
         """Run f_i on the current stream and f_hv on a side stream, then join.  `shared` = tensors read by
         both (allocator bookkeeping for cross-stream use)."""
         if not self._two(shared[0]):
             return f_i(), f_hv()
         main = torch.cuda.current_stream()
-        side = getattr(self, "_side_stream", None)
-        if side is None or side.device != shared[0].device:
-            side = torch.cuda.Stream(device=shared[0].device)
-            object.__setattr__(self, "_side_stream", side)
+        side = self._side(shared[0].device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             out_hv = f_hv()
@@ -144,10 +169,7 @@ class CIDNet(nn.Module, _HubMixin):
         main = side = None
         if two:
             main = torch.cuda.current_stream()
-            side = getattr(self, "_side_stream", None)
-            if side is None or side.device != i.device:
-                side = torch.cuda.Stream(device=i.device)
-                object.__setattr__(self, "_side_stream", side)
+            side = self._side(i.device)
             side.wait_stream(main)
 
         def on_side(f):
@@ -177,10 +199,7 @@ class CIDNet(nn.Module, _HubMixin):
     def _backpressure(self, x):
         if not (x.is_cuda and self.max_queued_forwards > 0) or torch.cuda.is_current_stream_capturing():
             return
-        q = getattr(self, "_fwd_events", None)
-        if q is None:
-            q = []
-            object.__setattr__(self, "_fwd_events", q)
+        q = _runtime(self, x.device)["events"]
         while len(q) >= self.max_queued_forwards:
             q.pop(0).synchronize()
         ev = torch.cuda.Event()

@@ -71,7 +71,7 @@ class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, n_buckets: int = 4, loss_fn: Optional[Callable] = None,
                  process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = True, use_graph: bool = False,
-                 max_steps_in_flight: int = 3, max_queued_bytes: int = 96 << 30):
+                 max_steps_in_flight: int = 3, max_queued_bytes: Optional[int] = None):
         self.model = model
         # Back-pressure.  Nothing in a training step synchronises host and device, and the host enqueues a step in ~13 ms
         # while the GPU needs ~31 ms.  Root cause of the multi-second stalls of round 1 (tools/stall_probe.py,
@@ -85,7 +85,8 @@ class DataParallelTrainer:
         # or larger activations per step (TNSM, the full objective, bigger batches) is covered as well.
         # Three steps, not two: a queue of two steps (62 ms of work) is drained by an ordinary 65 ms host hiccup.
         self.max_steps_in_flight = max(1, int(max_steps_in_flight))
-        self.max_queued_bytes = int(max_queued_bytes)
+        # None: a third of the device's memory, resolved at the first step (96 GiB on a 288 GB MI355X)
+        self.max_queued_bytes = None if max_queued_bytes is None else int(max_queued_bytes)
         self._step_events = []
         self.loss_fn = loss_fn or _default_loss
         self.pg = process_group
@@ -188,6 +189,8 @@ class DataParallelTrainer:
             for p in mem:
                 self._bucket_of[id(p)] = bi
         self._pending = [0] * len(self.buckets)
+        self._ln_uses = [st for st in ln_uses if st.acc]
+        self._check_layout_across_ranks(layout, n_live)
         # 4) gradients written in place by the HIP backward kernels (single-use parameters only)
         multi = [p.data_ptr() for p in live if id(p) in multi_ids]      # pointers AFTER re-homing into flat_p
         if self.use_hip:
@@ -198,6 +201,51 @@ class DataParallelTrainer:
             p.register_post_accumulate_grad_hook(self._on_grad)
         self.opt = FlatAdam(self.flat_p, kernel=self.use_hip, **self._opt_args)
         self._ready = True
+
+    def _check_layout_across_ranks(self, layout, n_live):
+        """Every rank derives the arena layout from its OWN probing backward (gradient-ready order).  The order is a
+        property of the graph, so it is the same everywhere -- but if it ever were not (a data-dependent branch, another
+        library version on one node), the all-reduce would silently add different parameters into each other.  Rank 0
+        broadcasts a digest of (parameter name, offset, size) in layout order plus the bucket cuts; a mismatch raises."""
+        if not (self.world > 1 or self._force_comm):
+            return
+        import hashlib
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        h = hashlib.sha256()
+        for p in layout:
+            off, n = self._slices[id(p)]
+            h.update(f"{names.get(id(p), '?')}:{off}:{n};".encode())
+        h.update(f"live={n_live};buckets={[(s0, c) for s0, c, _ in self.buckets]}".encode())
+        mine = torch.tensor(list(h.digest()), dtype=torch.int64, device=self.flat_g.device)
+        ref = mine.clone()
+        dist.broadcast(ref, src=0, group=self.pg)
+        same = torch.equal(mine.cpu(), ref.cpu())
+        flag = torch.tensor([0 if same else 1], dtype=torch.int64, device=self.flat_g.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.pg)
+        if int(flag.item()) != 0:
+            raise RuntimeError(f"rank {self.rank}: gradient-arena layout differs between ranks "
+                               f"({'this rank differs from rank 0' if not same else 'another rank differs'}); "
+                               "the bucket all-reduce would mix parameters")
+
+    def _begin_pass(self, x):
+        """state every forward+backward starts from: all gradients of every bucket pending, no collective in flight, and
+        the in-place LayerNorm gradient counters at zero -- a stray grad-mode forward without a backward (validation
+        without no_grad, model(x) for logging, an exception between forward and backward) would otherwise leave
+        `fwd` ahead of `bwd` for good and the LayerNorm gradients would never be handed over again."""
+        for bi, (_, _, mem) in enumerate(self.buckets):
+            self._pending[bi] = len(mem)
+        self._handles = []
+        self._main_stream = torch.cuda.current_stream() if x.is_cuda else None
+        for st in self._ln_uses:
+            st.fwd = st.bwd = 0
+
+    def _end_pass(self):
+        """every live parameter's gradient must have arrived in the arena (and its bucket been launched)"""
+        if any(self._pending):
+            missing = [i for i, n in enumerate(self._pending) if n]
+            raise RuntimeError(f"backward left gradients pending in buckets {missing}: a parameter that received a gradient "
+                               "in the probing step got none now (graph changed?), or a LayerNorm's uses were not all "
+                               "run backward")
 
     def _join_wgrad_stream(self):
         """make the current stream wait for the weight-gradient stream (ops._offload_wgrad)"""
@@ -255,12 +303,10 @@ class DataParallelTrainer:
 
     # ---- hipGraph replay of forward + loss + backward ---------------------------------------------
     def _fwd_bwd(self, x, gt):
-        for bi, (_, _, mem) in enumerate(self.buckets):
-            self._pending[bi] = len(mem)
-        self._handles = []
-        self._main_stream = torch.cuda.current_stream() if x.is_cuda else None
+        self._begin_pass(x)
         loss = self.loss_fn(self.model(x), gt)
         loss.backward()
+        self._end_pass()
         return loss
 
     def _capture(self, x, gt):
@@ -307,8 +353,11 @@ class DataParallelTrainer:
         if x.is_cuda:
             while len(self._step_events) >= self.max_steps_in_flight:
                 self._step_events.pop(0).synchronize()
-            # bytes pinned for queued work = "active" (in use or waiting for a stream event) minus what the host still holds
-            while self._step_events and self._queued_bytes(x.device) > self.max_queued_bytes:
+            # bytes pinned for queued work = "active" (in use or waiting for a stream event) minus what the host still holds;
+            # only looked at while more than one step is queued (the stats call walks the allocator's counters)
+            if self.max_queued_bytes is None:
+                self.max_queued_bytes = torch.cuda.get_device_properties(x.device).total_memory // 3
+            while len(self._step_events) > 1 and self._queued_bytes(x.device) > self.max_queued_bytes:
                 self._step_events.pop(0).synchronize()
         if self.use_graph and x.is_cuda:
             loss = self._graph_step(x, gt)
@@ -327,19 +376,17 @@ class DataParallelTrainer:
 
     @staticmethod
     def _queued_bytes(device):
-        st = torch.cuda.memory_stats(device)
-        return st.get("active_bytes.all.current", 0) - st.get("allocated_bytes.all.current", 0)
+        st = torch.cuda.memory_stats_as_nested_dict(device)
+        return st["active_bytes"]["all"]["current"] - st["allocated_bytes"]["all"]["current"]
 
     def forward_backward(self, x, gt):
         """forward + loss + backward only (gradients left in the flat arena); for timing splits."""
         if not self._ready:
             self._setup(x, gt)
-        for bi, (_, _, mem) in enumerate(self.buckets):
-            self._pending[bi] = len(mem)
-        self._handles = []
-        self._main_stream = torch.cuda.current_stream() if x.is_cuda else None
+        self._begin_pass(x)
         loss = self.loss_fn(self.model(x), gt)
         loss.backward()
+        self._end_pass()
         for h in self._handles:
             h.wait()
         self._join_wgrad_stream()

@@ -155,8 +155,9 @@ class CIDNetLoss(nn.Module):
     `model` supplies HVIT for the HVI-space terms, exactly as train.py calls `model.HVIT` on the output and on the ground
     truth.  The perceptual term is built as train.py:192 does: conv1_2 / conv2_2 / conv3_4 / conv4_4, 'mse'."""
 
-    def __init__(self, model, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0, P_weight=0.0):
+    def __init__(self, model, L1_weight=1.0, D_weight=0.5, E_weight=50.0, HVI_weight=1.0, P_weight=0.0, tnsm_weight=0.0):
         super().__init__()
+        self.tnsm_weight = tnsm_weight
         self.l1 = L1Loss(loss_weight=L1_weight)
         self.ssim = SSIM(weight=D_weight)
         self.edge = EdgeLoss(loss_weight=E_weight)
@@ -172,7 +173,19 @@ class CIDNetLoss(nn.Module):
             t = t + self.p_weight * self.perceptual(a, b)[0]
         return t
 
-    def forward(self, output_rgb, gt_rgb):
+    def forward(self, output_rgb, gt_rgb, noise_map=None, im1=None):
+        """`noise_map`, `im1`: the second result of CIDNet_TNSM.forward in train mode and the network input; with
+        tnsm_weight > 0 they add train_tnsm.py:68-72's  tnsm_weight * (noise_consistency_loss + noise_smoothing_loss)."""
         loss_hvi = self._terms(self._hvit(output_rgb), self._hvit(gt_rgb))
         loss_rgb = self._terms(output_rgb, gt_rgb)
-        return loss_rgb + self.hvi_weight * loss_hvi
+        loss = loss_rgb + self.hvi_weight * loss_hvi
+        if self.tnsm_weight > 0 and noise_map is not None:
+            if im1 is None:
+                raise ValueError("CIDNetLoss: the TNSM noise terms need the network input im1 (train_tnsm.py:69)")
+            loss = loss + tnsm_noise_loss(noise_map, output_rgb, im1, self.tnsm_weight)
+        return loss
+
+
+def tnsm_noise_loss(noise_map, output_rgb, im1, weight=1.0):
+    """weight * (noise_consistency_loss + noise_smoothing_loss), train_tnsm.py:68-72 (options.py:61: tnsm_weight = 1)"""
+    return ops.TNSMNoiseLossFn.apply(noise_map, output_rgb, im1.detach(), float(weight))

@@ -293,9 +293,9 @@ def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None)
                _p(ws), ws.numel(), B, C, H, W, _stream())
 
 
-# Opt-in: run the dense 3x3 convs with K = 36 input channels on the BF16 matrix cores with exact three-way split operands
-# (csrc/conv3s.hip: results within fp32 rounding of the fp32-MFMA kernel, error against fp64 equal or smaller).  Off by
-# default: at M = K = 36 it measures 515-540 us against the fp32 kernel's 505-535 us at 8x36x400x600.
+# Dense 3x3 convs whose input-channel count is a multiple of 36 (all of CIDNet's 36 / 72 / 144-channel layers) run on the
+# BF16 matrix cores with exact three-way split operands (csrc/conv3x.hip: results within fp32 rounding of the fp32-MFMA
+# kernel, error against fp64 equal or smaller).  CIDNET_CONV3_BF16X3=0 selects the fp32-MFMA kernel (csrc/conv3.hip).
 CONV3_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_BF16X3", "0") == "1"}
 
 
@@ -303,8 +303,10 @@ def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, add
     """y = conv3x3(x) (+ addend, in the kernel's epilogue; only for layers with more than 4 channels on both sides)"""
     if CONV3_BF16X3["on"] and not replicate and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
             and CONV3_BF16X3.get("filter", lambda *a: True)(M, K, H, W):
+        n = _raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)
+        ws = _ws(n, x.device)
         lib().call("cidnet_conv3x3_bf16x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), _p(addend), M * H * W, _p(y), M * H * W,
-                   B, M, K, H, W, _stream())
+                   _p(ws), ws.numel(), B, M, K, H, W, _stream())
         return
     if addend is None:
         lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
@@ -923,6 +925,35 @@ class EdgeLossFn(torch.autograd.Function):
             gy = torch.empty_like(gx)
             lib().call("cidnet_scale", _p(gx), None, _f(-1.0), _p(gy), gx.numel(), _stream())
         return (gx if ctx.needs_input_grad[0] else None), gy, None
+
+
+class TNSMNoiseLossFn(torch.autograd.Function):
+    """weight * (noise_consistency_loss + noise_smoothing_loss) of the TNSM training script (train_tnsm.py:68-72):
+    consistency = mean|noise_map - (1 - sigmoid(mean_c|output_rgb - im1|))|, smoothing = mean|d_x| + mean|d_y| of the
+    map.  Differentiable in noise_map and output_rgb (im1 is the network's input, never a leaf that needs it)."""
+
+    @staticmethod
+    def forward(ctx, noise_map, output_rgb, im1, weight):
+        _check(noise_map, output_rgb, im1)
+        noise_map, output_rgb, im1 = _c(noise_map), _c(output_rgb), _c(im1)
+        B, C, H, W = noise_map.shape
+        if output_rgb.shape != (B, 3, H, W) or im1.shape != output_rgb.shape:
+            raise RuntimeError("TNSM noise loss: noise_map (B,C,H,W) with output_rgb / im1 (B,3,H,W)")
+        need_n, need_o = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_n = torch.empty_like(noise_map) if need_n else None
+        g_o = torch.empty_like(output_rgb) if need_o else None
+        loss = torch.empty((), device=noise_map.device, dtype=torch.float32)
+        n = _raw("cidnet_tnsm_noise_loss_ws_floats")
+        ws = _ws(n, noise_map.device)
+        lib().call("cidnet_tnsm_noise_loss", _p(noise_map), _p(output_rgb), _p(im1), _f(weight), _p(loss), _p(g_n), _p(g_o), _p(ws),
+                   ws.numel(), B, C, H, W, _stream())
+        ctx.save_for_backward(g_n, g_o)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g_n, g_o = ctx.saved_tensors
+        return (_scaled(g_n, g, 1.0) if g_n is not None else None, _scaled(g_o, g, 1.0) if g_o is not None else None, None, None)
 
 
 # VGG19 feature stack up to conv4_4 (loss/vgg_arch.py:105-110: names; torchvision cfg 'E'): (name, Cin, Cout) or "pool"

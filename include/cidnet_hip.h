@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CIDNET_ABI_VERSION 1
+#define CIDNET_ABI_VERSION 3
 
 int cidnet_abi_version(void);
 
@@ -184,13 +184,16 @@ void cidnet_debug_c3_flags(int flags);
 #endif
 int cidnet_conv3x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip,
                    int replicate, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
-/* The same zero-pad convolution with its fp32 operands split into three bf16 values each and the six significant
- * cross products run on the BF16 matrix cores (csrc/conv3s.hip): results within fp32 rounding of cidnet_conv3x3
- * (products exact, fp32 accumulation, dropped terms <= 2^-25 relative), on a pipe the VALU does not contend for.
- * R optional addend (batch stride r_bs).  _supported: shapes the kernel is instantiated for (K <= 40). */
+/* The same zero-pad convolution (net/transformer_utils.py:39,58 and its data gradient) with its fp32 operands split
+ * into three bf16 values each and the six significant cross products run on the BF16 matrix cores (csrc/conv3x.hip):
+ * results within fp32 rounding of cidnet_conv3x3 (products exact, fp32 accumulation, dropped terms <= 2^-25 relative),
+ * on a pipe the VALU does not contend for.  R optional addend (batch stride r_bs).  ws (cidnet_conv3x3_bf16x3_ws_floats
+ * floats, 16-byte aligned) receives the split weights in MFMA fragment order.  _supported: K a multiple of 36. */
 int cidnet_conv3x3_bf16x3_supported(int M, int K);
+long cidnet_conv3x3_bf16x3_ws_floats(int M, int K);
 int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, const float* R,
-                          long r_bs, float* Y, long y_bs, int B, int M, int K, int H, int W, void* stream);
+                          long r_bs, float* Y, long y_bs, float* ws, long ws_floats, int B, int M, int K, int H,
+                          int W, void* stream);
 /* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
  * NormDownsample when its input also feeds a skip connection (net/CIDNet.py:80-81,85-86): the skip's gradient is
  * added in the epilogue instead of by a separate pass over the tensor.  Layers with <= 4 channels on a side
@@ -340,6 +343,16 @@ int cidnet_resize_bilinear_fwd(const float* src, float* dst, long dst_bs, int B,
                                int Ho, int Wo, void* stream);
 int cidnet_resize_bilinear_bwd(const float* gdst, long gdst_bs, float* gsrc, int B, int C, int Hi,
                                int Wi, int Ho, int Wo, void* stream);
+
+/* ---- the TNSM variant's extra objective (train_tnsm.py:68-72) ---------------------------------------------------
+ * loss = weight * (mean|noise_map - (1 - sigmoid(mean_c|out_rgb - im|))| + mean|d_x noise_map| + mean|d_y noise_map|),
+ * noise_map (B,C,H,W) = the fused noise map CIDNet_TNSM.forward returns in train mode (C = 3), out_rgb / im (B,3,H,W).
+ * One pass: loss (device scalar) and the gradients wrt noise_map and out_rgb (either may be NULL).
+ * ws: cidnet_tnsm_noise_loss_ws_floats() floats. */
+long cidnet_tnsm_noise_loss_ws_floats(void);
+int cidnet_tnsm_noise_loss(const float* noise_map, const float* out_rgb, const float* im, float weight, float* loss,
+                           float* g_noise, float* g_out, float* ws, long ws_floats, int B, int C, int H, int W,
+                           void* stream);
 
 #ifdef __cplusplus
 }

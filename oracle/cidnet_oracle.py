@@ -392,6 +392,17 @@ def edge_loss(x: torch.Tensor, y: torch.Tensor, weight: float = 1.0) -> torch.Te
     return F.mse_loss(edge_laplacian(x), edge_laplacian(y)) * weight
 
 
+def tnsm_noise_losses(noise_map: torch.Tensor, output_rgb: torch.Tensor, im1: torch.Tensor):
+    """(noise_consistency_loss, noise_smoothing_loss) of the TNSM training script, train_tnsm.py:68-70.  PARITY UNPINNED:
+    the formula lives inline in a script whose imports (torchvision datasets) fail here, so this is a restatement of
+    those three lines from the text; F.sigmoid there is torch.sigmoid."""
+    target = 1.0 - torch.sigmoid(torch.mean(torch.abs(output_rgb - im1), dim=1, keepdim=True))
+    consistency = torch.mean(torch.abs(noise_map - target))
+    smoothing = (torch.mean(torch.abs(noise_map[:, :, :, :-1] - noise_map[:, :, :, 1:]))
+                 + torch.mean(torch.abs(noise_map[:, :, :-1, :] - noise_map[:, :, 1:, :])))
+    return consistency, smoothing
+
+
 # --------------------------------------------------------------------------------------
 # whole network
 # --------------------------------------------------------------------------------------

@@ -186,3 +186,51 @@ def test_dp_two_ranks_cidnet_tree_match_single_process_adam():
         # Adam's first steps move every weight by ~lr regardless of gradient scale: compare against lr
         assert d <= 2e-2 * 1e-3 + 1e-7, (n, d)
     print("worst |delta| vs single-process Adam:", worst)
+
+
+class NetSwapped(Net):
+    """same parameters as Net, but the two halves of the forward are ordered so that gradients become ready in another
+    order: a rank running this module derives a different arena layout"""
+
+    def forward(self, x):
+        return super().forward(x) + 0.0 * self.dead(torch.zeros(1, 4)).sum()      # `dead` now receives a (zero) gradient
+
+
+def _worker_layout(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    torch.manual_seed(5)
+    net = Net() if rank == 0 else NetSwapped()
+    tr = DataParallelTrainer(net, lr=1e-2, n_buckets=2, loss_fn=l1, use_hip_kernels=False)
+    x, gt = torch.rand(2, 3, 8, 8), torch.rand(2, 3, 8, 8)
+    try:
+        tr.step(x, gt)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_layout_mismatch_between_ranks_raises():
+    """every rank derives the gradient-arena layout from its own probing backward; if two ranks ever
+    disagree, the bucket all-reduce would add different parameters into each other silently.  The trainer now compares a
+    digest of the layout across ranks in _setup and raises on every rank."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_layout, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "layout differs between ranks" in res[0], res
+    assert "layout differs between ranks" in res[1], res

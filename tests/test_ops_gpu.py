@@ -324,13 +324,15 @@ def test_bf16_storage_mode_whole_model(dev):
     assert worst <= 0.15, (worst, wname)          # measured 0.079 (a depthwise weight gradient summed over bf16-rounded du)
 
 
-@pytest.mark.parametrize("B,M,K,H,W,flip,add", [(2, 36, 36, 37, 51, 0, 0), (1, 12, 12, 9, 70, 1, 0), (2, 72, 36, 20, 33, 0, 1), (1, 36, 36, 64, 96, 1, 1),
-                                                (1, 24, 24, 5, 7, 0, 0), (2, 100, 36, 12, 40, 0, 0)])
+@pytest.mark.parametrize("B,M,K,H,W,flip,add", [(2, 36, 36, 37, 51, 0, 0), (2, 72, 36, 20, 33, 0, 1), (1, 36, 36, 64, 96, 1, 1),
+                                                (2, 100, 36, 12, 40, 0, 0), (1, 36, 72, 21, 150, 1, 0), (1, 144, 72, 13, 75, 0, 1),
+                                                (1, 72, 144, 10, 75, 1, 0), (3, 36, 36, 8, 32, 0, 0), (1, 5, 36, 1, 1, 0, 0)])
 def test_conv3x3_bf16x3_split_products(dev, B, M, K, H, W, flip, add):
-    """csrc/conv3s.hip: the zero-pad 3x3 conv on the BF16 matrix cores with every fp32 operand split exactly into three bf16
+    """csrc/conv3x.hip: the zero-pad 3x3 conv on the BF16 matrix cores with every fp32 operand split exactly into three bf16
     values and the six significant cross products accumulated in fp32.  Against the fp64 convolution its error must not
     exceed the fp32-MFMA kernel's (x1.5 + 1e-6 of the output scale): forward and data-gradient (flipped, transposed
-    weights) forms, addend epilogue, ragged sizes, more than one block of output channels."""
+    weights) forms, addend epilogue, ragged sizes (rows of 75 / 150 pixels end inside a pixel quad), several 48-channel
+    output chunks and 36-channel input chunks; every output element written (NaN prefill) and reruns bit-identical."""
     from hvi_cidnet_amd import ops
     import torch.nn.functional as F
     g = torch.Generator(device=dev).manual_seed(B * 1000 + M + H)
@@ -347,15 +349,19 @@ def test_conv3x3_bf16x3_split_products(dev, B, M, K, H, W, flip, add):
     if add:
         ref = ref + r.double().cpu()
     assert ops._raw("cidnet_conv3x3_bf16x3_supported", M, K) == 1
-    y32, ys = torch.empty(B, M, H, W, device=dev), torch.empty(B, M, H, W, device=dev)
+    y32 = torch.empty(B, M, H, W, device=dev)
+    ys, ys2 = torch.full((B, M, H, W), float("nan"), device=dev), torch.full((B, M, H, W), float("nan"), device=dev)
     old = dict(ops.CONV3_BF16X3)
     try:
         ops.CONV3_BF16X3["on"] = False
         ops.conv3x3(x, wt, y32, B, M, K, H, W, w_ms, w_ks, flip=bool(flip), addend=r)
         ops.CONV3_BF16X3["on"] = True
         ops.conv3x3(x, wt, ys, B, M, K, H, W, w_ms, w_ks, flip=bool(flip), addend=r)
+        ops.conv3x3(x, wt, ys2, B, M, K, H, W, w_ms, w_ks, flip=bool(flip), addend=r)
     finally:
         ops.CONV3_BF16X3.update(old)
+    assert not torch.isnan(ys).any()
+    assert torch.equal(ys, ys2)
     e32 = (y32.cpu().double() - ref).abs().max().item()
     es = (ys.cpu().double() - ref).abs().max().item()
     assert es <= 1.5 * e32 + 1e-6 * ref.abs().max().item(), (es, e32)

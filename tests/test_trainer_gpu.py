@@ -86,6 +86,60 @@ def test_trainer_gradients_and_update_match_plain_autograd(dev, chans, shape):
     ops.enable_wgrad_stream(False)
 
 
+def test_trainer_survives_stray_grad_mode_forward(dev):
+    """a grad-enabled forward WITHOUT a backward between two trainer steps (validation without
+    no_grad, model(x) for logging) used to leave the in-place LayerNorm gradient counters with fwd ahead of bwd for good:
+    the 22 live LayerNorm gradients were then never handed to autograd, their bucket never completed and stale values
+    piled up in the arena -- silently.  The trainer zeroes the counters at the start of every pass and raises when a
+    bucket is left pending; the gradients of the step after the stray forward must equal plain autograd's."""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    chans, shape = (12, 12, 24, 48), (2, 3, 32, 48)
+    x = O.synthetic_batch(41, shape).to(dev)
+    gt = O.synthetic_batch(42, shape).to(dev)
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
+    ref = _model(dev, chans)
+    ref.two_streams = False
+    ops.L1LossFn.apply(ref(x), gt).backward()
+    grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
+    m = _model(dev, chans)
+    tr = DataParallelTrainer(m, lr=0.0, n_buckets=3, wgrad_stream=True)       # lr 0: the weights stay the reference's
+    tr.step(x, gt)
+    y_stray = m(x)                                                           # grad mode, never run backward
+    assert y_stray.requires_grad
+    uses = [mod._use for mod in m.modules() if hasattr(mod, "_use")]
+    assert any(st.fwd != st.bwd for st in uses)                              # the counters ARE out of balance now
+    tr.forward_backward(x, gt)
+    torch.cuda.synchronize()
+    names = {id(p): n for n, p in m.named_parameters()}
+    for p in tr.params:
+        n = names[id(p)]
+        if n not in grads:
+            continue
+        off, cnt = tr._slices[id(p)]
+        got = tr.flat_g[off:off + cnt].view(p.shape)
+        err = (got - grads[n]).abs().max().item()
+        assert err <= 1e-5 * grads[n].abs().max().item() + 1e-8, f"{n}: {err:.3e}"
+    del y_stray
+    ops.set_grad_arena(None, None)
+    ops.enable_wgrad_stream(False)
+
+
+def test_model_deepcopy_and_save_after_forward(dev, tmp_path):
+    """streams / events used by the two-stream forward and its back-pressure live outside the module, so
+    a model that has run stays copy.deepcopy()-able (EMA copies) and torch.save()-able; the copy computes the same."""
+    import copy
+    m = _model(dev, (12, 12, 24, 48))
+    x = O.synthetic_batch(43, (1, 3, 32, 48)).to(dev)
+    with torch.no_grad():
+        y = m(x)
+        m2 = copy.deepcopy(m)
+        torch.save(m, tmp_path / "model.pt")
+        assert torch.equal(m2(x), y)
+    assert m._side_stream is not None
+
+
 def test_trainer_rccl_path_on_one_rank(dev, monkeypatch):
     """The multi-GPU code path (bucket all-reduces launched from gradient hooks, joined with the weight-gradient
     stream, 1/world folded into Adam) exercised on ONE rank over RCCL: a 1-rank all-reduce is the identity, so
