@@ -12,10 +12,18 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "libcidnet_hip.so")
+OBJ = os.environ.get("CIDNET_OBJ_DIR") or os.path.join(CSRC, "build")
+LIB = os.environ.get("CIDNET_LIB_OUT") or os.path.join(HERE, "libcidnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+# No packed-fp32 (v_pk_fma/mul/add_f32) and no SDWA instructions anywhere in the library: beside waves that feed bf16 MFMAs
+# from LDS (csrc/conv3x.hip, on by default since round 3; csrc/pws.hip) a packed-fp32 op with op_sel in ANOTHER kernel's
+# waves was seen to lose one of its two products (tools/mfma_pk_probe.hip), and the two branch
+# streams / the weight-gradient stream make any kernel a possible neighbour.  The feature switch removes the instructions
+# at the source (-fno-slp-vectorize alone leaves the ones that come from float4 arithmetic); SDWA shares the operand-select
+# path.  The host pass of hipcc prints "not a recognized feature" for the switch and ignores it (filtered below).
+NO_PACKED = [] if os.environ.get("CIDNET_ALLOW_PACKED") else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+                                                               "-mllvm", "-amdgpu-sdwa-peephole=0"]      # (unrestricted build: A/B only)
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *NO_PACKED,
           "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC, *os.environ.get("CIDNET_EXTRA_FLAGS", "").split()]
 # hvi.hip mirrors the reference's fp32 operation order (bit-exact masks/sextants): no implicit FMA
 # dw.hip: the SLP vectoriser packs the stencil FMAs into v_pk_fma_f32 and pays for it with register-pair shuffles
@@ -23,8 +31,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # iel.hip: same for the stencil stages of the tile-resident IEL kernel
 PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] if not os.environ.get("CIDNET_DW_SLP") else [],
             "iel.hip": ["-fno-slp-vectorize"],
-            # split-product kernels: no packed-fp32 / SDWA instructions beside LDS-fed bf16 MFMAs
-            "conv3x.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sdwa-peephole=0", *os.environ.get("CIDNET_C3X_FLAGS", "").split()],
+            "conv3x.hip": ["-fno-slp-vectorize", *os.environ.get("CIDNET_C3X_FLAGS", "").split()],
             "conv3_thin.hip": os.environ.get("CIDNET_THIN_FLAGS", "").split()}
 
 
@@ -48,8 +55,9 @@ def _compile(src, force):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    err = "\n".join(l for l in r.stderr.splitlines() if "is not a recognized feature for this target" not in l)
+    if err.strip():
+        sys.stderr.write(err + "\n")
     return obj, True
 
 

@@ -115,12 +115,11 @@ class CIDNet(nn.Module, _HubMixin):
     two_streams = True
 
     def _two(self, t):
-        # The opt-in bf16x3 kernels (ops.CONV3_BF16X3 / ops.PW_BF16X3: csrc/conv3s.hip, csrc/pws.hip) must not share a CU with
-        # the other branch's kernels: next to bf16-MFMA waves the packed-fp32 FMAs of the stem conv were seen to drop single
-        # products (tools/c3s_batch_probe.py), so those modes run the two branches one after the other.
-        bf16_mfma = (ops.CONV3_BF16X3["on"] and not ops.CONV3_BF16X3.get("allow_two_streams")) or \
-            (ops.PW_BF16X3["on"] and not ops.PW_BF16X3.get("allow_two_streams"))
-        return self.two_streams and t.is_cuda and not bf16_mfma
+        # (Round 2 serialised the branches while a bf16-MFMA kernel was enabled: beside LDS-fed bf16 MFMAs, packed-fp32
+        # instructions with op_sel in another kernel's waves were seen to drop products.  Since round 3 the library is built
+        # without packed-fp32 and SDWA instructions -- hvi-cidnet_amd/build.py, checked by tests/test_abi.py -- and the
+        # split-product 3x3 conv is on by default, on both streams.)
+        return self.two_streams and t.is_cuda
 
     def _side(self, device):
         st = _runtime(self, device)

@@ -27,7 +27,14 @@
 //  * Every wave computes ALL THREE 16-channel tiles of the chunk for its 64 pixels (2 rows x 32): a B fragment feeds 18
 //    MFMAs.  N-tile e of a wave holds pixel e of each of its 16 pixel quads, so a lane ends up with four consecutive
 //    pixels of a channel row: float4 stores (and float4 loads of the optional addend).
-//  * Blocks are persistent (two per CU, 73 KB of LDS each): one stages while the other computes.
+//  * Blocks are persistent (two per CU, 73 KB of LDS each): one stages while the other computes; the second half of the
+//    grid starts late so that the pairs do not run in lockstep (worth 3 %).
+// Measured on MI355X (8 x 36 -> 36 x 400 x 600): 362-384 us against the fp32-MFMA kernel's 527-542 us; the k loop with
+// everything but its 792 MFMAs per tile removed takes 240 us (profiles/r03_b_conv3x_ablation_single_wave_pipeline.txt):
+// under bf16-MFMA load the chip sustains ~1.6 GHz, and 31 % of the issued MFMA work is padding (36 -> 48 channels, 324 ->
+// 352 k).  A one-block-per-CU variant that pipelined everything inside one wave per SIMD (512 registers, double-buffered
+// tiles, split and output stores interleaved with the MFMAs) measured 395 us: every stalled load or store stops that
+// SIMD's only wave; loading a tile's activations in one batch instead of two rounds at a time measured slower too.
 // No packed-fp32 / SDWA instructions: built with -fno-slp-vectorize -mllvm -amdgpu-sdwa-peephole=0.
 #include "common.h"
 
@@ -69,6 +76,7 @@ struct X3Args {
   float* Y; long y_bs;
   int B, M, K, H, W;
   int tiles_x, tiles_y, mchunks, kchunks;
+  int stagger;                         // start delay of the second half of the grid, in units of s_sleep 64
 };
 
 // exact three-way split of two fp32 values into packed bf16 pairs (lo half = a, hi half = b), round to nearest even
@@ -191,16 +199,23 @@ __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
   const int qrow = 2 * wave + (n >> 3), qcol = 4 * (n & 7);
   const unsigned pbase = (unsigned)((qrow * T::RP + qcol * KCH) * 2);
 
-  const int tiles_per_img = a.tiles_x * a.tiles_y;
-  const long nwork = (long)a.B * tiles_per_img * a.mchunks;
+  const unsigned tiles_per_img = a.tiles_x * a.tiles_y;
+  const unsigned nwork = (unsigned)a.B * tiles_per_img * a.mchunks;
   // work ids are dealt so that the blocks of one XCD (ids 8 apart share an L2) walk neighbouring tiles
-  const int per_xcd = gridDim.x >> 3;
-  const long first = (gridDim.x & 7) ? blockIdx.x : (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned first = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  // Two blocks share a CU and alternate "stage" and "k loop" phases.  Started together they stay in lockstep (both stage,
+  // then both share the matrix pipe): the second half of the grid -- the blocks that land in the CUs' second slots --
+  // starts late, so that one block stages while the other computes.  The offset persists: a block's period does not
+  // depend on its phase.
+  if (blockIdx.x >= (gridDim.x >> 1) && a.stagger > 0) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
 
-  for (long work = first; work < nwork; work += gridDim.x) {
-    const int mc = (int)(work % a.mchunks);
-    const long tile = work / a.mchunks;
-    const int b = (int)(tile / tiles_per_img), tr = (int)(tile - (long)b * tiles_per_img);
+  for (unsigned work = first; work < nwork; work += gridDim.x) {
+    const int mc = (int)(work % (unsigned)a.mchunks);
+    const unsigned tile = work / (unsigned)a.mchunks;
+    const int b = (int)(tile / tiles_per_img), tr = (int)(tile - (unsigned)b * tiles_per_img);
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
     const int y0 = ty * kXTH, x0 = tx * kXTW;
 
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
             const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * q;
             const bool row_in = gy >= 0 && gy < H;
             const float* src = xb + (long)(4 * cg) * HW + (long)(row_in ? gy : 0) * W;
-            float v[4][4];                                     // [channel][pixel]
+            float v[4][4];                                   // [channel][pixel]
             if (row_in && gx0 >= 0 && gx0 + 3 < W && q > 0 && q < NQ - 1) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int lc = 4 * q + j - 3;                    // column inside the staged tile
+              const int lc = 4 * q + j - 3;                  // column inside the staged tile
               if (lc < 0 || lc >= kXPW) continue;
               unsigned p0a, p1a, p2a, p0b, p1b, p2b;
               split3_pair(v[0][j], v[1][j], p0a, p1a, p2a);
@@ -359,6 +374,7 @@ int launch_conv3x(const float* Wt, long w_ms, long w_ks, int flip, X3Args a, flo
   const long nwork = (long)a.B * a.tiles_x * a.tiles_y * a.mchunks;
   long nblk = 512;                                            // persistent: two resident blocks per CU
   if (nblk > nwork) nblk = nwork;
+  a.stagger = 2;                                              // ~8k cycles: about the length of a staging phase
   hipLaunchKernelGGL((conv3x_kernel<KCH>), dim3((unsigned)nblk), dim3(kXThreads), T::LDS_BYTES, s, a);
   return CIDNET_OK;
 }
@@ -382,7 +398,7 @@ int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms,
                           float* Y, long y_bs, float* ws, long ws_floats, int B, int M, int K, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(X && Wt && Y && ws && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
   if (!cidnet_conv3x3_bf16x3_supported(M, K)) return CIDNET_ERR_SHAPE;
-  X3Args a{X, x_bs, nullptr, R, r_bs, Y, y_bs, B, M, K, H, W, 0, 0, 0, 0};
+  X3Args a{X, x_bs, nullptr, R, r_bs, Y, y_bs, B, M, K, H, W, 0, 0, 0, 0, 0};
   const int rc = launch_conv3x<36>(Wt, w_ms, w_ks, flip, a, ws, ws_floats, (hipStream_t)stream);
   if (rc != CIDNET_OK) return rc;
   CIDNET_LAUNCH_STATUS();

@@ -240,10 +240,8 @@ def _pe(t, off_elems=0):
 # Opt-in: 1x1 convs that are bound by the fp32 MFMA rate run on the BF16 matrix cores with exact three-way split operands
 # (csrc/pws.hip).  Taken for the launches where it measures faster than pw.hip (tools/micro_pws.py: reduction-heavy shapes,
 # K >= 1.9 M or K >= M >= 288 -- 1.2-1.9x; shapes with more output than input channels lose to the scalar stores and
-# the per-chunk re-split).  Off by default: +1.2 % on the step, and next to bf16-MFMA waves the packed-fp32 stem conv
-# needs a build without v_pk_* ops.
-PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "0") == "1",
-             "allow_two_streams": os.environ.get("CIDNET_BF16X3_TWO_STREAMS", "0") == "1"}
+# the per-chunk re-split).  Off by default: +1.2 % on the step.
+PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "0") == "1"}
 
 
 def pw_bf16x3_wins(M, K):
@@ -296,7 +294,7 @@ def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None)
 # Dense 3x3 convs whose input-channel count is a multiple of 36 (all of CIDNet's 36 / 72 / 144-channel layers) run on the
 # BF16 matrix cores with exact three-way split operands (csrc/conv3x.hip: results within fp32 rounding of the fp32-MFMA
 # kernel, error against fp64 equal or smaller).  CIDNET_CONV3_BF16X3=0 selects the fp32-MFMA kernel (csrc/conv3.hip).
-CONV3_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_BF16X3", "0") == "1"}
+CONV3_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_BF16X3", "1") == "1"}
 
 
 def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None):

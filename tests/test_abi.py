@@ -43,3 +43,27 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_library_has_no_packed_fp32_or_sdwa_instructions(tmp_path):
+    """The shipped code objects contain no v_pk_{fma,mul,add}_f32 and no SDWA instruction (hvi-cidnet_amd/build.py): beside
+    LDS-fed bf16 MFMAs (csrc/conv3x.hip runs on both branch streams) packed-fp32 ops with op_sel in a neighbouring
+    kernel's waves were seen to drop products (tools/mfma_pk_probe.hip)."""
+    import glob
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    from hvi_cidnet_amd import _lib
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not present")
+    lib = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    cos = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert len(cos) >= 15, cos
+    mfma = 0
+    for co in cos:
+        dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        bad = [l for l in dis.splitlines() if "sdwa" in l or any(f"v_pk_{op}_f32" in l for op in ("fma", "mul", "add"))]
+        assert not bad, (co, bad[:3])
+        mfma += dis.count("v_mfma_f32_16x16x32_bf16")
+    assert mfma > 0          # the split-product kernels are in the library

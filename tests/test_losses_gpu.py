@@ -179,11 +179,12 @@ def test_cidnet_loss_with_perceptual_term(dev):
     assert torch.isfinite(out.grad).all() and out.grad.abs().max().item() > 0
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 3, 9, 7), (2, 3, 8, 1), (1, 3, 1, 12), (1, 3, 64, 96)])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 3, 9, 7), (2, 3, 8, 2), (1, 3, 2, 12), (1, 3, 64, 96)])
 def test_tnsm_noise_objective_vs_oracle(dev, shape):
     """train_tnsm.py:68-72 on device (VERDICT r2 missing #1): weight * (noise_consistency_loss + noise_smoothing_loss) and
     its gradients wrt the fused noise map and wrt output_rgb against the fp64 oracle restatement (parity unpinned: the
-    formula is inline in a script that cannot be imported), even / odd / one-row / one-column sizes."""
+    formula is inline in a script that cannot be imported), even / odd / two-row / two-column sizes (with a single row
+    or column the reference formula is the mean of an empty tensor, NaN; the network never produces such maps)."""
     import hvi_cidnet_amd as P
     B, C, H, W = shape
     nm = O.synthetic_batch(301, shape)

@@ -358,12 +358,6 @@ def test_two_streams_bit_identical_to_single_stream(dev, storage):
         P.set_storage_dtype("f32")
 
 
-experimental = pytest.mark.skipif(os.environ.get("CIDNET_TEST_EXPERIMENTAL", "0") != "1",
-                                  reason="opt-in bf16x3 kernels inside the whole model: set CIDNET_TEST_EXPERIMENTAL=1.  The conv variant "
-                                         "failed its rerun-equality check in 1 of 7 runs on MI355X (DESIGN.md section 4 (i)); the "
-                                         "kernels themselves are covered by the op-level tests in test_ops_gpu.py")
-
-
 def _dump_rerun_mismatch(tag, ys, y32):
     """Failing-run evidence: positions (b, c, y, x) and values of every element that differs
     between reruns, written under gpurun_out/ (merged back from the GPU box) -- copy it to profiles/ when it appears."""
@@ -386,11 +380,11 @@ def _dump_rerun_mismatch(tag, ys, y32):
         f.write("\n".join(lines) + "\n")
 
 
-@experimental
 def test_cidnet_with_bf16x3_conv(dev):
-    """Opt-in split-product conv (ops.CONV3_BF16X3, csrc/conv3s.hip) inside the whole model: output within fp32 rounding of
-    the default path (2e-6 absolute on outputs in [0, 1]) and reproducible.  The mode serialises the two branches
-    (CIDNet._two): concurrently with the kernel's waves the stem conv was seen to drop products."""
+    """The split-product conv (ops.CONV3_BF16X3, csrc/conv3x.hip: the default) inside the whole model at 8x3x400x600 with
+    both branch streams on: output within fp32 rounding of the fp32-MFMA conv path (2e-6 absolute on outputs in [0, 1])
+    and three runs bit-identical.  A mismatch writes the differing elements' positions and values under gpurun_out/
+    (round 2's kernel, csrc/conv3s.hip, failed this rerun check once in seven runs; it was replaced)."""
     import hvi_cidnet_amd as P
     from hvi_cidnet_amd import ops
     m = P.CIDNet()
@@ -417,7 +411,6 @@ def test_cidnet_with_bf16x3_conv(dev):
     assert (ys[0] - y32).abs().max().item() <= 2e-6
 
 
-@experimental
 def test_cidnet_with_bf16x3_pw_conv(dev):
     """Opt-in split-product 1x1 conv (ops.PW_BF16X3, csrc/pws.hip) inside the whole model, forward and backward: output and
     gradients within fp32 rounding of the default path, and reproducible."""

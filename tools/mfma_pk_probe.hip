@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256, 2) void aggressor(float* out, int iters) {
                      "v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
                      "v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(r) : "v"(q));
         acc[j][0] = __uint_as_float(r & 0x3fffffffu);
+      } else if (KIND == 7) {                                    // two ds_read_b64 per fragment, as conv3x.hip (round 3), feeding bf16 MFMAs
+        const char* base = reinterpret_cast<const char*>(lds) + (((threadIdx.x * 9 + it * 64 + j * 256) & 4095) * 8);
+        unsigned long long lo, hi;
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"((unsigned)(size_t)base));
+        const uint4 f = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, f), acc[j], 0, 0, 0);
       } else {                                                   // LDS fragment reads, as conv3s.hip: feeding bf16 MFMAs (4), VALU (5), fp32 MFMAs (6)
         const u32x4 f = *(volatile u32x4*)&lds[(threadIdx.x * 7 + it * 64 + j * 256) & 2047];
         if (KIND == 4) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, f), acc[j], 0, 0, 0);
@@ -126,6 +132,8 @@ int main() {
     row<3, 1>("beside SDWA stream, 200-VGPR waves", bad, out, sv, sa);
     row<4, 0>("beside LDS b128 reads + bf16 MFMA", bad, out, sv, sa);
     row<4, 1>("beside LDS reads + bf16 MFMA, 200-VGPR waves", bad, out, sv, sa);
+    row<7, 0>("beside LDS 2 x b64 reads + bf16 MFMA", bad, out, sv, sa);
+    row<7, 1>("beside LDS 2 x b64 reads + bf16 MFMA, 200 VGPRs", bad, out, sv, sa);
     row<5, 1>("beside LDS reads + VALU, 200-VGPR waves", bad, out, sv, sa);
     row<6, 1>("beside LDS reads + fp32 MFMA, 200-VGPR waves", bad, out, sv, sa);
   }
