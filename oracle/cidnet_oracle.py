@@ -152,19 +152,26 @@ def bilinear_ac(x: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
 
 
 def norm_downsample(x, p: Params, pre: str):
-    """`NormDownsample.forward`, net/transformer_utils.py:38-43 (use_norm=False path)."""
+    """`NormDownsample.forward`, net/transformer_utils.py:38-48; the `use_norm` LayerNorm (:44-46, after the PReLU) is
+    applied when the parameter set holds `<pre>.norm.*` (CIDNet(norm=True), net/CIDNet.py:12)."""
     y = F.conv2d(x, p[pre + ".down.0.weight"], padding=1)
     y = bilinear_ac(y, (int(math.floor(y.shape[2] * 0.5)), int(math.floor(y.shape[3] * 0.5))))
-    return F.prelu(y, p[pre + ".prelu.weight"])
+    y = F.prelu(y, p[pre + ".prelu.weight"])
+    if pre + ".norm.weight" in p:
+        y = layernorm_cf(y, p[pre + ".norm.weight"], p[pre + ".norm.bias"])
+    return y
 
 
 def norm_upsample(x, skip, p: Params, pre: str):
-    """`NormUpsample.forward`, net/transformer_utils.py:62-70 (use_norm=False path)."""
+    """`NormUpsample.forward`, net/transformer_utils.py:62-70; with `<pre>.norm.*` present the `use_norm` LayerNorm (:67-68)."""
     y = F.conv2d(x, p[pre + ".up_scale.0.weight"], padding=1)
     y = bilinear_ac(y, (y.shape[2] * 2, y.shape[3] * 2))
     y = torch.cat([y, skip], dim=1)
     y = F.conv2d(y, p[pre + ".up.weight"])
-    return F.prelu(y, p[pre + ".prelu.weight"])
+    y = F.prelu(y, p[pre + ".prelu.weight"])
+    if pre + ".norm.weight" in p:
+        y = layernorm_cf(y, p[pre + ".norm.weight"], p[pre + ".norm.bias"])
+    return y
 
 
 def rep_conv3x3(x, w):
@@ -475,19 +482,26 @@ def cidnet_forward(p: Params, x: torch.Tensor, heads=(1, 2, 4, 8), this_k: Optio
 # --------------------------------------------------------------------------------------
 # deterministic, torch-RNG-independent parameters
 # --------------------------------------------------------------------------------------
-def param_shapes(channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), variant: str = "base") -> Dict[str, Tuple[int, ...]]:
+def param_shapes(channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), variant: str = "base", norm: bool = False) -> Dict[str, Tuple[int, ...]]:
     """Names and shapes of the reference's 191 state_dict tensors (net/CIDNet.py:17-69),
     in the reference's registration order; variant="mssa" appends the six SpatialAttention convs
-    (net/CIDNet_MSSA.py:91-97) for 197 tensors."""
+    (net/CIDNet_MSSA.py:91-97) for 197 tensors; norm=True adds the LayerNorm of every down / up block
+    (CIDNet(norm=True): net/transformer_utils.py:35-36,54-55; 24 more tensors)."""
     c1, c2, c3, c4 = channels
     _, h2, h3, h4 = heads
     s: Dict[str, Tuple[int, ...]] = {}
 
     def down(pre, ci, co):
+        if norm:
+            s[pre + ".norm.weight"] = (co,)
+            s[pre + ".norm.bias"] = (co,)
         s[pre + ".prelu.weight"] = (1,)
         s[pre + ".down.0.weight"] = (co, ci, 3, 3)
 
     def up(pre, ci, co):
+        if norm:
+            s[pre + ".norm.weight"] = (co,)
+            s[pre + ".norm.bias"] = (co,)
         s[pre + ".prelu.weight"] = (1,)
         s[pre + ".up_scale.0.weight"] = (co, ci, 3, 3)
         s[pre + ".up.weight"] = (co, 2 * co, 1, 1)
@@ -582,7 +596,7 @@ def _key_seed(seed: int, key: str) -> int:
 
 
 def make_params(seed: int = 0, channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), jitter: bool = True,
-                dtype=torch.float32, variant: str = "base") -> Params:
+                dtype=torch.float32, variant: str = "base", norm: bool = False) -> Params:
     """Counter-based deterministic parameters w = f(seed, key, shape) from numpy's PCG64 (stable
     across numpy/torch versions).  Conv weights ~ U(+-1/sqrt(fan_in)) (PyTorch's default
     Kaiming-uniform a=sqrt(5) bound).  With `jitter` the unit/zero-initialised tensors (LayerNorm
@@ -590,7 +604,7 @@ def make_params(seed: int = 0, channels=(36, 36, 72, 144), heads=(1, 2, 4, 8), j
     parameter; without it they take the reference's init values (1/0, 0.25, 1, 0.2)."""
     import numpy as np
     out: Params = {}
-    for key, shape in param_shapes(channels, heads, variant).items():
+    for key, shape in param_shapes(channels, heads, variant, norm).items():
         rng = np.random.Generator(np.random.PCG64(_key_seed(seed, key)))
         u = rng.random(shape, dtype=np.float64) * 2.0 - 1.0
         if re.search(r"norm\d*\.weight$", key):

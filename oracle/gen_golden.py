@@ -681,7 +681,85 @@ def gen_fullsize():
     print("wrote fullsize.npz", len(out), "arrays")
 
 
+def gen_round3():
+    """Round-3 fixtures, written to tests/golden/round3.npz:
+    (d) CIDNet(norm=True) -- the LayerNorm option of every down / up block (net/CIDNet.py:12, net/transformer_utils.py:
+        44-48, 66-70) -- reduced width, forward + every gradient through the imported reference;
+    (c) BASELINE configs[4] at its image size: 1x3x400x600 forward of CIDNet_MSSA and CIDNet_TNSM (train mode: rgb and the
+        fused noise map) through the imported reference, strided outputs + checksums; for TNSM also the fp64 oracle's
+        output (its un-normalised attention saturates the softmax, net/TNSM.py:98-104)."""
+    out = {}
+    # ---- (d) ----
+    chans = (12, 12, 24, 48)
+    p = O.make_params(13, channels=chans, norm=True)
+
+    def make():
+        mm = RefCIDNet(channels=list(chans), norm=True)
+        load_into(mm, p)
+        return mm
+    shp = (2, 3, 32, 48)
+    seed, margin = pick_input_seed(make, shp, lambda mm, xx: mm(xx))
+    m = make()
+    assert len(m.state_dict()) == 191 + 24
+    x, gt = O.synthetic_batch(seed, shp), O.synthetic_batch(seed + 1, shp)
+    yr = m(x)
+    (yr - gt).abs().mean().backward()
+    po = O.params_to(p, requires_grad=True)
+    yo = O.cidnet_forward(po, x)
+    (yo - gt).abs().mean().backward()
+    check_equal(yo, yr, "CIDNet(norm=True) fwd")
+    out.update(norm_x=x.numpy(), norm_gt=gt.numpy(), norm_out=yr.detach().numpy(), norm_kink_margin=np.float64(margin))
+    worst, dead = 0.0, []
+    for n, prm in m.named_parameters():
+        if prm.grad is None:
+            dead.append(n)
+            assert po[n].grad is None, n
+            continue
+        worst = max(worst, (prm.grad - po[n].grad).abs().max().item() / max(prm.grad.abs().max().item(), 1e-30))
+        out[f"norm_g.{n}"] = prm.grad.numpy()
+    assert all(n.startswith("I_LCA5.") for n in dead), dead
+    print(f"  ok  CIDNet(norm=True) grads: worst rel-to-max diff oracle vs reference {worst:.2e}; kink margin {margin:.2e}")
+    assert worst < 1e-4
+    # ---- (c) ----
+    from net.CIDNet_MSSA import CIDNet as RefMSSA
+    from net.CIDNet_TNSM import CIDNet_TNSM as RefTNSM
+    shape = (1, 3, 400, 600)
+    x = O.synthetic_batch(181, shape)
+    pm = O.make_params(5, variant="mssa")
+    m = RefMSSA()
+    load_into(m, pm)
+    with torch.no_grad():
+        ym = m(x)
+        check_equal(O.cidnet_forward(pm, x, variant="mssa"), ym, "CIDNet_MSSA fwd 1x3x400x600")
+    out["mssa400_out_strided"] = ym[:, :, ::8, ::8].numpy()
+    yd = ym.double()
+    out["mssa400_out_sums"] = np.array([yd.sum().item(), yd.abs().sum().item(), (yd ** 2).sum().item()])
+    pt = O.make_params(5, variant="tnsm")
+    m = RefTNSM()
+    load_into(m, pt)
+    m.train()
+    with torch.no_grad():
+        yt, ft = m(x)
+        yo, fo = O.cidnet_tnsm_forward(pt, x)
+        check_equal(yo, yt, "CIDNet_TNSM fwd rgb 1x3x400x600")
+        check_equal(fo, ft, "CIDNet_TNSM fwd fused noise 1x3x400x600")
+        y64, f64 = O.cidnet_tnsm_forward(O.params_to(pt, dtype=torch.float64), x.double())
+    out["tnsm400_out_strided"] = yt[:, :, ::8, ::8].numpy()
+    out["tnsm400_noise_strided"] = ft[:, :, ::8, ::8].numpy()
+    out["tnsm400_out64_strided"] = y64[:, :, ::8, ::8].float().numpy()
+    out["tnsm400_noise64_strided"] = f64[:, :, ::8, ::8].float().numpy()
+    yd = yt.double()
+    out["tnsm400_out_sums"] = np.array([yd.sum().item(), yd.abs().sum().item(), (yd ** 2).sum().item()])
+    print(f"  TNSM 400x600: reference fp32 vs fp64 oracle: rgb {(yt.double() - y64).abs().max().item():.2e}, "
+          f"noise {(ft.double() - f64).abs().max().item():.2e}")
+    np.savez_compressed(os.path.join(GOLD, "round3.npz"), **out)
+    print("wrote round3.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":
+        gen_round3()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mssa":
         gen_mssa()
         sys.exit(0)
@@ -705,5 +783,6 @@ if __name__ == "__main__":
     gen_losses()
     gen_lr_schedule()
     gen_fullsize()
+    gen_round3()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

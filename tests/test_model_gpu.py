@@ -135,6 +135,30 @@ def test_cidnet_golden(golden, dev, tag, chans):
     assert n_checked > 30
 
 
+def test_cidnet_norm_option_golden(golden, dev):
+    """CIDNet(norm=True): the LayerNorm option of the down / up blocks (net/CIDNet.py:12, net/transformer_utils.py:44-48,
+    66-70; VERDICT r2 missing #4) against the reference's output and every gradient (tests/golden/round3.npz)"""
+    import hvi_cidnet_amd as P
+    g = golden("round3")
+    chans = (12, 12, 24, 48)
+    p = O.make_params(13, channels=chans, norm=True)
+    m = P.CIDNet(channels=list(chans), norm=True)
+    assert len(m.state_dict()) == 191 + 24
+    load(m, p)
+    m.to(dev)
+    y = m(_t(g["norm_x"], dev))
+    out_ok(y, g["norm_out"], 1e-4, "CIDNet(norm=True) fwd")
+    (y - _t(g["norm_gt"], dev)).abs().mean().backward()
+    n = 0
+    for name, prm in m.named_parameters():
+        if name.startswith("I_LCA5."):
+            assert prm.grad is None
+            continue
+        grad_ok(prm.grad, g[f"norm_g.{name}"], rel=2e-4, what=f"norm=True d{name}")
+        n += 1
+    assert n == 191 + 24 - 13
+
+
 def test_cidnet_config1_400x600(golden, dev):
     """config 1 of BASELINE.json: one 1x3x400x600 forward, default-style parameters"""
     import hvi_cidnet_amd as P

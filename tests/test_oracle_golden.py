@@ -195,3 +195,31 @@ def test_fullsize_oracle_matches_reference_fixture(golden):
     for name, v in p.items():
         if name not in dead:
             _fp_close(g, "tnsm", name, v.grad)
+
+
+def test_oracle_norm_option_matches_reference(golden):
+    """CIDNet(norm=True) (net/CIDNet.py:12; the LayerNorm of every down / up block, net/transformer_utils.py:44-48,66-70):
+    the oracle against the reference's output and gradients in round3.npz"""
+    g = golden("round3")
+    chans = (12, 12, 24, 48)
+    p = O.params_to(O.make_params(13, channels=chans, norm=True), requires_grad=True)
+    assert len(p) == 191 + 24
+    y = O.cidnet_forward(p, _t(g["norm_x"]))
+    assert torch.equal(y.detach(), _t(g["norm_out"]))
+    (y - _t(g["norm_gt"])).abs().mean().backward()
+    n = 0
+    for k, v in p.items():
+        if k.startswith("I_LCA5."):
+            assert v.grad is None
+            continue
+        _close(v.grad, g[f"norm_g.{k}"], rel=1e-5)
+        n += 1
+    assert n == 191 + 24 - 13
+
+
+def test_oracle_mssa_400x600_forward_matches_reference(golden):
+    """BASELINE configs[4] image size: the oracle's CIDNet_MSSA forward at 1x3x400x600 against the reference's"""
+    g = golden("round3")
+    with torch.no_grad():
+        y = O.cidnet_forward(O.make_params(5, variant="mssa"), O.synthetic_batch(181, (1, 3, 400, 600)), variant="mssa")
+    assert torch.equal(y[:, :, ::8, ::8], _t(g["mssa400_out_strided"]))
