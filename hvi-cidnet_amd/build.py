@@ -32,6 +32,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] if not os.environ.get("CIDNET_DW_SLP") else [],
             "iel.hip": ["-fno-slp-vectorize"],
             "conv3x.hip": ["-fno-slp-vectorize", *os.environ.get("CIDNET_C3X_FLAGS", "").split()],
+            "pwx.hip": ["-fno-slp-vectorize"],
             "conv3_thin.hip": os.environ.get("CIDNET_THIN_FLAGS", "").split()}
 
 

@@ -237,15 +237,17 @@ def _pe(t, off_elems=0):
     return _vp(t.data_ptr() + t.element_size() * int(off_elems))
 
 
-# Opt-in: 1x1 convs that are bound by the fp32 MFMA rate run on the BF16 matrix cores with exact three-way split operands
-# (csrc/pws.hip).  Taken for the launches where it measures faster than pw.hip (tools/micro_pws.py: reduction-heavy shapes,
-# K >= 1.9 M or K >= M >= 288 -- 1.2-1.9x; shapes with more output than input channels lose to the scalar stores and
-# the per-chunk re-split).  Off by default: +1.2 % on the step.
-PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "0") == "1"}
+# 1x1 convs that the fp32 MFMA rate bounds (many channels on small planes) or that reduce over many channels run on the BF16
+# matrix cores with exact three-way split operands (csrc/pwx.hip).  Taken where it measures faster than pw.hip
+# (tools/micro_pwx.py, profiles/r03_d_micro_pwx.txt: reduction-heavy shapes 1.2-1.7x; shapes that fan out to many output
+# channels from few inputs stay on pw.hip, they are store-bound either way).  CIDNET_PW_BF16X3=0 switches it off.
+PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "1") == "1"}
 
 
-def pw_bf16x3_wins(M, K):
-    return K >= 144 and (K >= 1.9 * M or (K >= M and M >= 288))
+def pw_bf16x3_wins(M, K, HW=0):
+    if HW and HW < 8000 and M * K <= 144 * 144:
+        return False
+    return K >= 95 or (K >= 72 and 72 <= M <= 150) or (M == 72 and K == 36)
 
 
 def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
@@ -258,7 +260,7 @@ def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B
 def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
     """x / y may be bf16 tensors (offsets and strides in elements)"""
     if PW_BF16X3["on"] and x.dtype == torch.float32 and y.dtype == torch.float32 \
-            and pw_bf16x3_wins(M, K) \
+            and pw_bf16x3_wins(M, K, HW) \
             and _raw("cidnet_pw_conv_bf16x3_supported", M, K, HW):
         return pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res, r_off, r_bs)
     lib().call("cidnet_pw_conv_t", _pe(x, x_off), _dt(x), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _pe(y, y_off), _dt(y), y_bs,

@@ -369,14 +369,15 @@ def test_conv3x3_bf16x3_split_products(dev, B, M, K, H, W, flip, add):
 
 @pytest.mark.parametrize("B,M,K,HW,res,form", [
     (2, 144, 766, 3750, False, "fwd"), (2, 766, 144, 3750, True, "fwd"), (3, 72, 382, 1501, True, "fwd"),
-    (2, 36, 36, 999, False, "fwd"), (1, 16, 32, 64, False, "fwd"), (2, 191, 72, 777, False, "dgrad"),
-    (2, 144, 144, 1000, True, "per_sample"), (1, 5, 7, 19, True, "fwd")])
+    (2, 36, 36, 999, False, "fwd"), (1, 20, 32, 64, False, "fwd"), (2, 191, 72, 777, False, "dgrad"),
+    (2, 144, 144, 1000, True, "per_sample"), (1, 17, 7, 19, True, "fwd"), (2, 95, 36, 4, True, "fwd"), (1, 288, 288, 3750, False, "dgrad")])
 def test_pw_conv_bf16x3_split_products(dev, B, M, K, HW, res, form):
-    """csrc/pws.hip: the 1x1 conv on the BF16 matrix cores with exact three-way split operands against the fp64 product;
+    """csrc/pwx.hip: the 1x1 conv on the BF16 matrix cores with exact three-way split operands against the fp64 product;
     bar = 3x the fp32-MFMA kernel's own error + 2e-6 of the output scale (the matrix core's fp32 accumulation of six
     products per term is a little looser than the fp32 MFMA at K = 766: 5e-6 against 1.3e-6).  Shapes: every block layout
-    (1, 2, 4 waves along M; 1-3 channel tiles per wave; several channel chunks), ragged pixel / channel / K tails, the
-    data-gradient weight strides and per-sample weights (attention fold)."""
+    (2, 4 waves along M; 1-3 channel tiles per wave; several channel chunks), ragged pixel / channel / K tails (planes whose
+    size is not a multiple of 4 or of 64, a 4-pixel plane), the data-gradient weight strides and per-sample weights
+    (attention fold); every output element written (NaN prefill) and a rerun bit-identical."""
     from hvi_cidnet_amd import ops
     g = torch.Generator(device=dev).manual_seed(M * 7 + K)
     x = torch.randn(B, K, HW, device=dev, generator=g)
@@ -404,6 +405,9 @@ def test_pw_conv_bf16x3_split_products(dev, B, M, K, HW, res, form):
     finally:
         ops.PW_BF16X3.update(old)
     ops.pw_conv_bf16x3(x, 0, K * HW, w, 0, w_bs, w_ms, w_ks, ys, 0, M * HW, B, M, K, HW, res=r, r_off=0, r_bs=M * HW)
+    ys2 = torch.full((B, M, HW), float("nan"), device=dev)
+    ops.pw_conv_bf16x3(x, 0, K * HW, w, 0, w_bs, w_ms, w_ks, ys2, 0, M * HW, B, M, K, HW, res=r, r_off=0, r_bs=M * HW)
+    assert not torch.isnan(ys).any() and torch.equal(ys, ys2)
     e32 = (y32.cpu().double() - ref).abs().max().item()
     es = (ys.cpu().double() - ref).abs().max().item()
     assert es <= 3 * e32 + 2e-6 * ref.abs().max().item(), (es, e32)

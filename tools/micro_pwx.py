@@ -1,4 +1,4 @@
-"""fp32-MFMA 1x1 conv (pw.hip) vs the bf16x3 split-product kernel (pws.hip) at the step's shapes: time and error against
+"""fp32-MFMA 1x1 conv (pw.hip) vs the bf16x3 split-product kernel (pwx.hip) at the step's shapes: time and error against
 fp64 (dev tool)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,8 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 shapes = [(144, 766, 3750), (766, 144, 3750), (288, 288, 3750), (144, 383, 3750), (383, 144, 3750), (144, 144, 3750), (144, 288, 3750),
           (288, 144, 3750), (72, 382, 15000), (72, 191, 15000), (382, 72, 15000), (144, 144, 15000), (72, 72, 15000), (72, 144, 15000),
-          (144, 72, 15000), (191, 72, 15000), (72, 72, 60000), (36, 190, 60000), (190, 36, 60000), (36, 36, 60000)]
+          (144, 72, 15000), (191, 72, 15000), (72, 72, 60000), (36, 190, 60000), (190, 36, 60000), (36, 36, 60000), (36, 95, 60000),
+          (95, 36, 60000), (72, 36, 60000), (36, 72, 60000), (36, 36, 240000)]
 if len(sys.argv) > 1: shapes = shapes[:int(sys.argv[1])]
 B = 8
 torch.manual_seed(0)
