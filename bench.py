@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (the 2:1-sparsity figure is twice that)
 
 
 def parse():
@@ -113,6 +114,32 @@ def conv3x3_flops(args):
     # cidnet_conv3x3(X, x_bs, Wt, w_ms, w_ks, flip, replicate, Y, y_bs, B, M, K, H, W, stream)
     B, M, K, H, W = args[9], args[10], args[11], args[12], args[13]
     return 2.0 * 9 * M * K * H * W * B
+
+
+def conv3x_flops(args):
+    # cidnet_conv3x3_bf16x3(X, x_bs, Wt, w_ms, w_ks, flip, R, r_bs, Y, y_bs, ws, ws_floats, B, M, K, H, W, stream)
+    B, M, K, H, W = args[12], args[13], args[14], args[15], args[16]
+    return 2.0 * 9 * M * K * H * W * B
+
+
+def pw_work(name, args):
+    """(algorithmic FLOPs, algorithmic HBM bytes: every operand once) of one launch of the 1x1-conv family, from the call's
+    own arguments (include/cidnet_hip.h); None for other entry points"""
+    es = lambda dt: 2 if dt else 4
+    if name == "cidnet_pw_conv_t":        # (X, x_dt, x_bs, Wt, w_bs, w_ms, w_ks, Y, y_dt, y_bs, R, r_bs, B, M, K, HW, stream)
+        x_dt, y_dt, R, B, M, K, HW = args[1], args[8], args[10], args[12], args[13], args[14], args[15]
+        return 2.0 * M * K * HW * B, (K * es(x_dt) + M * es(y_dt) + (M * 4 if R is not None else 0)) * HW * B
+    if name == "cidnet_pw_conv_bf16x3":   # (X, x_bs, Wt, w_bs, w_ms, w_ks, Y, y_bs, R, r_bs, ws, ws_floats, B, M, K, HW, stream)
+        R, B, M, K, HW = args[8], args[12], args[13], args[14], args[15]
+        return 2.0 * M * K * HW * B, (K + M + (M if R is not None else 0)) * 4 * HW * B
+    if name == "cidnet_pw_conv_up_prelu":  # (skip, x_bs, Wt, w_ms, w_ks, Z, slope, Y, Ypre, B, M, K, zh, zw, stream)
+        Ypre, B, M, K, zh, zw = args[8], args[9], args[10], args[11], args[12], args[13]
+        hw = 4 * zh * zw
+        return 2.0 * M * K * hw * B, ((K + M + (M if Ypre is not None else 0)) * hw + M * zh * zw) * 4 * B
+    if name == "cidnet_pw_wgrad_t":       # (dY, dy_dt, dy_bs, X, x_dt, x_bs, dW, dw_ld, per_sample, acc, ws, ws_floats, B, M, N, HW, stream)
+        dy_dt, x_dt, B, M, N, HW = args[1], args[4], args[12], args[13], args[14], args[15]
+        return 2.0 * M * N * HW * B, (M * es(dy_dt) + N * es(x_dt)) * HW * B
+    return None
 
 
 def relaunch_ranks(a):
@@ -323,19 +350,50 @@ def main():
                if name == "cidnet_conv3x3_add" and min(args[12], args[13]) > 4]
         c3_flops = sum(conv3x3_flops(ar) for ar, _ in c3)
         c3_ms = sum(ms for _, ms in c3)
-        achieved = c3_flops / (c3_ms * 1e-3) / 1e12 if c3_ms > 0 else 0.0
+        # the same convs on the bf16 matrix cores (csrc/conv3x.hip, the default): six bf16 products per fp32 product
+        cx = [(args, e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if name == "cidnet_conv3x3_bf16x3"]
+        cx_flops = sum(conv3x_flops(ar) for ar, _ in cx)
+        cx_ms = sum(ms for _, ms in cx)
         if a.op_table:
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {k:40s} calls/step {v[0] // 2:5d}  ms/step {v[1] / 2:9.3f}  {100 * v[1] / tot:5.1f}%", file=sys.stderr)
             print(f"  sum of kernel families: {tot / 2:.3f} ms/step; wall {1e3 * dt / a.steps:.3f} ms/step", file=sys.stderr)
             for k, v in sorted(timer.table(by_shape=True).items(), key=lambda kv: -kv[1][1])[:a.op_rows]:
                 print(f"    {k:70s} x{v[0] // 2:3d}  {v[1] / 2:8.3f} ms", file=sys.stderr)
-        roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3 / _add: dense 3x3 fwd + dgrad, MFMA launches)",
-                "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(), "traffic_source": PMC_TRAFFIC_FILE,
-                "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
-                "measured_in": "2 extra single-stream steps after the timed region (HIP events per launch)",
-                "share_of_step_kernel_time": round(c3_ms / tot, 3) if tot else None}
+        if cx_ms > c3_ms:
+            # fp32-equivalent (algorithmic) rate, and the rate of the bf16 MFMA work it issues for it against the dense bf16 peak
+            eq = cx_flops / (cx_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv3x_kernel (cidnet_conv3x3_bf16x3: dense 3x3 fwd + dgrad as six exact bf16 "
+                                               "products per fp32 product on v_mfma_f32_16x16x32_bf16)",
+                    "achieved": round(6 * eq, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(6 * eq / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "fp32_equivalent_tflops": round(eq, 2), "vs_fp32_mfma_peak": round(eq / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": pmc_traffic("conv3x"), "traffic_source": PMC_TRAFFIC_FILE,
+                    "launches_per_step": len(cx) // 2, "avg_launch_ms": round(cx_ms / max(len(cx), 1), 4),
+                    "measured_in": "2 extra single-stream steps after the timed region (HIP events per launch)",
+                    "share_of_step_kernel_time": round(cx_ms / tot, 3) if tot else None,
+                    "note": "frac counts algorithmic products only: the kernel pads 36 -> 48 output channels and 324 -> 352 k "
+                            "(0.69 of its issued MFMAs are algorithmic) and the chip sustains ~1.6 GHz under bf16-MFMA load"}
+        else:
+            achieved = c3_flops / (c3_ms * 1e-3) / 1e12 if c3_ms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "conv3_kernel (cidnet_conv3x3 / _add: dense 3x3 fwd + dgrad, fp32 MFMA launches)",
+                    "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("conv3"), "traffic_source": PMC_TRAFFIC_FILE,
+                    "launches_per_step": len(c3) // 2, "avg_launch_ms": round(c3_ms / max(len(c3), 1), 4),
+                    "measured_in": "2 extra single-stream steps after the timed region (HIP events per launch)",
+                    "share_of_step_kernel_time": round(c3_ms / tot, 3) if tot else None}
+
+        # the family that bounds the step: the 1x1 convs and their weight gradients
+        pw = [(pw_work(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if pw_work(name, args) is not None]
+        pw_fl, pw_by, pw_ms = sum(w[0] for w, _ in pw), sum(w[1] for w, _ in pw), sum(t for _, t in pw)
+        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3, cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t)",
+                   "achieved": round(pw_by / (pw_ms * 1e-3) / 1e9, 1) if pw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": round(pw_by / (pw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if pw_ms > 0 else 0.0,
+                   "tflops": round(pw_fl / (pw_ms * 1e-3) / 1e12, 2) if pw_ms > 0 else 0.0,
+                   "vs_fp32_mfma_peak": round(pw_fl / (pw_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if pw_ms > 0 else 0.0,
+                   "traffic": pmc_traffic("pw"), "traffic_source": PMC_TRAFFIC_FILE, "launches_per_step": len(pw) // 2,
+                   "alg_gb_per_step": round(pw_by / 2 / 1e9, 3), "alg_gflop_per_step": round(pw_fl / 2 / 1e9, 1),
+                   "ms_per_step": round(pw_ms / 2, 3), "share_of_step_kernel_time": round(pw_ms / tot, 3) if tot else None}
 
         # the HBM-bound side: the streaming kernels of the IEL chain (the tensors the bf16 storage mode halves)
         hb = [(iel_stream_bytes(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
@@ -362,7 +420,8 @@ def main():
             "vs_baseline": None, "dtype": "f32" if a.dtype == "f32" else "bf16 storage of the IEL hidden tensors, f32 arithmetic", "data": "synthetic",
             "config": {"workload": f"CIDNet fwd+bwd bs={a.batch}/GPU 3x{a.height}x{a.width} fp32 (BASELINE.json configs[1])",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
-            "roofline": roof if a.dtype == "f32" else dict(roof_hbm, mfma_conv3=roof), "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
+            "roofline": roof if a.dtype == "f32" else dict(roof_hbm, mfma_conv3=roof), "roofline_pw": roof_pw, "roofline_hbm": roof_hbm,
+            "cpu_baseline": cpu,
             "inference_1024": infer,
         }
         print(json.dumps(out), flush=True)
@@ -371,16 +430,16 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_conv3_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic_by_family.json"
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_conv3_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction);
-    counters cannot be read from inside this process, so this is null if the summary is absent."""
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family ("conv3x", "conv3", "pw") from the committed rocprofv3 PMC passes
+    (written by tools/pmc_family_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --steps 1 --single-stream`,
+    gfx950 x2 read correction); counters cannot be read from inside this process, so this is null if the summary is absent."""
     try:
         d = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
-        return int(d["avg_hbm_bytes_per_launch"])
+        return int(d["families"][family]["avg_hbm_bytes_per_launch"])
     except Exception:
         return None
 

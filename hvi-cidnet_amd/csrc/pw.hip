@@ -15,6 +15,7 @@
 // Weights (A operand) are tiny and staged once per K-chunk in LDS, k-major with a leading
 // dimension == 16 (mod 32) so the two k-rows of a 32-lane half hit disjoint banks.
 #include "common.h"
+#include "cidnet_hip.h"
 
 namespace cidnet {
 namespace {
@@ -779,9 +780,36 @@ struct WgArgs {
   float* slabs;         // [B][chunks][M*N]
   int M, N; long HW; int pch;   // pixels per block (multiple of 128)
   int nnb;              // number of n-blocks
+  int bf3;              // fp32 operands on the bf16 matrix cores (exact split products)
 };
 
-template <int MT, int NT, class DT>       // DT::X = type of dY, DT::Y = type of X
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+
+// eight fp32 values (this lane's eight consecutive pixels of one row = the eight k of its lane group in a 16x16x32 MFMA)
+// -> the row's fragment at three bf16 levels, v = l0 + l1 + l2 exactly (round to nearest, every remainder exact)
+__device__ __forceinline__ void wg_split8(const f32x4& lo, const f32x4& hi, uint4 (&f)[3]) {
+  auto pair = [](float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const wg_bf16x2 h0 = __builtin_convertvector(wg_f32x2{x, y}, wg_bf16x2);
+    p0 = __builtin_bit_cast(unsigned, h0);
+    const float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xFFFF0000u);
+    const wg_bf16x2 h1 = __builtin_convertvector(wg_f32x2{rx, ry}, wg_bf16x2);
+    p1 = __builtin_bit_cast(unsigned, h1);
+    const float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xFFFF0000u);
+    const wg_bf16x2 h2 = __builtin_convertvector(wg_f32x2{sx, sy}, wg_bf16x2);
+    p2 = __builtin_bit_cast(unsigned, h2);
+  };
+  pair(lo[0], lo[1], f[0].x, f[1].x, f[2].x);
+  pair(lo[2], lo[3], f[0].y, f[1].y, f[2].y);
+  pair(hi[0], hi[1], f[0].z, f[1].z, f[2].z);
+  pair(hi[2], hi[3], f[0].w, f[1].w, f[2].w);
+}
+
+// BF3: the products run on the BF16 matrix cores as six exact bf16 cross products per fp32 product (see conv3x.hip): a
+// lane's eight consecutive pixels of a row ARE its 16x16x32 fragment, so the loads do not change; 6 MFMAs of 16 cycles
+// replace 8 of 32 per tile pair and step, at 11 VALU instructions per loaded pixel pair for the split.
+template <int MT, int NT, class DT, bool BF3 = false>       // DT::X = type of dY, DT::Y = type of X
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   extern __shared__ float red[];                 // [4 waves][MT*NT*4 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -837,15 +865,35 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { bc[nt][0] = bv[nt][0]; bc[nt][1] = bv[nt][1]; }
     if (p + 128 < pend) load_step(p + 128);       // prefetch this wave's next 32-pixel step
+    if constexpr (BF3) {
+      uint4 af[MT][3], bf[NT][3];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int mt = 0; mt < MT; ++mt) wg_split8(ac[mt][0], ac[mt][1], af[mt]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int nt = 0; nt < NT; ++nt) wg_split8(bc[nt][0], bc[nt][1], bf[nt]);
+      // smallest terms first; the tile pairs interleave, so dependent MFMAs are MT * NT issues apart
+#define CIDNET_WG_TERM(AL, BL)                                                                                     \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)              \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, af[mt][AL]),            \
+                                                            __builtin_bit_cast(wg_bf16x8, bf[nt][BL]), acc[mt][nt], 0, 0, 0)
+      CIDNET_WG_TERM(2, 0);
+      CIDNET_WG_TERM(1, 1);
+      CIDNET_WG_TERM(0, 2);
+      CIDNET_WG_TERM(1, 0);
+      CIDNET_WG_TERM(0, 1);
+      CIDNET_WG_TERM(0, 0);
+#undef CIDNET_WG_TERM
+    } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt][h][e], bc[nt][h][e], acc[mt][nt], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt][h][e], bc[nt][h][e], acc[mt][nt], 0, 0, 0);
+    }
   }
 
   // sum the four waves' tiles through LDS, one slab per block
@@ -911,6 +959,12 @@ int launch_wg_dt(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
 // instantiated type pairs (dY, X): all fp32; a bf16 hidden tensor on either side
 template <int MT, int NT>
 int launch_wg(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
+  if (a.ddt == 0 && a.xdt == 0 && a.bf3) {
+    dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnb), (unsigned)B);
+    hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, PwDT<0, 0>, true>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
+    CIDNET_LAUNCH_STATUS();
+    return CIDNET_OK;
+  }
   if (a.ddt == 0 && a.xdt == 0) return launch_wg_dt<MT, NT, PwDT<0, 0>>(a, chunks, nmb, B, s);
   if (a.ddt == 1 && a.xdt == 0) return launch_wg_dt<MT, NT, PwDT<1, 0>>(a, chunks, nmb, B, s);
   if (a.ddt == 0 && a.xdt == 1) return launch_wg_dt<MT, NT, PwDT<0, 1>>(a, chunks, nmb, B, s);
@@ -999,20 +1053,22 @@ long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW) {
 }
 
 int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
-                      int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream);
+                      int per_sample, int flags, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream);
 
 int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld, int per_sample,
-                    int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
-  return cidnet_pw_wgrad_t(dY, 0, dy_bs, X, 0, x_bs, dW, dw_ld, per_sample, accumulate, ws, ws_floats, B, M, N, HW, stream);
+                    int flags, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
+  return cidnet_pw_wgrad_t(dY, 0, dy_bs, X, 0, x_bs, dW, dw_ld, per_sample, flags, ws, ws_floats, B, M, N, HW, stream);
 }
 
 int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
-                      int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
+                      int per_sample, int flags, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream) {
   CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && HW > 0 && (dy_dt | 1) == 1 && (x_dt | 1) == 1);
   if (ws_floats < cidnet_pw_wgrad_ws_floats(B, M, N, HW)) return CIDNET_ERR_WS;
   WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.ddt = dy_dt; a.X = X; a.x_bs = x_bs; a.xdt = x_dt; a.slabs = ws; a.M = M; a.N = N; a.HW = HW;
   a.pch = wgrad_pch(B, M, N, HW);
+  a.bf3 = (flags & CIDNET_WGRAD_FP32_MFMA) ? 0 : 1;
+  const int accumulate = flags & CIDNET_WGRAD_ACCUMULATE;
   const int chunks = (int)((HW + a.pch - 1) / a.pch);
   const int MT = pick_tiles(M, 3), NT = pick_tiles(N, 3);
   const int nmb = ((M + 15) / 16 + MT - 1) / MT;

@@ -267,11 +267,16 @@ def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K,
                _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, _stream())
 
 
+# The 1x1 weight gradients of fp32 operands run on the BF16 matrix cores as exact split products (csrc/pw.hip, pw_wgrad_kernel
+# <.., BF3>); CIDNET_PW_WGRAD_BF16X3=0 keeps them on the fp32 MFMA (flag CIDNET_WGRAD_FP32_MFMA of the C ABI).
+PW_WGRAD_BF16X3 = {"on": os.environ.get("CIDNET_PW_WGRAD_BF16X3", "1") == "1"}
+
+
 def pw_wgrad(dy, dy_off, dy_bs, x, x_off, x_bs, dw, dw_off, dw_ld, B, M, N, HW, per_sample=False):
     n = _raw("cidnet_pw_wgrad_ws_floats", B, M, N, HW)
     ws = _ws(n, dy.device)
     lib().call("cidnet_pw_wgrad_t", _pe(dy, dy_off), _dt(dy), dy_bs, _pe(x, x_off), _dt(x), x_bs, _po(dw, dw_off), dw_ld,
-               int(per_sample), 0, _p(ws), ws.numel(), B, M, N, HW, _stream())
+               int(per_sample), 0 if PW_WGRAD_BF16X3["on"] else 2, _p(ws), ws.numel(), B, M, N, HW, _stream())
 
 
 def dw3x3(inp, w1, w2, csplit, out, B, C, H, W, flip=False, addend=None):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CIDNET_ABI_VERSION 3
+#define CIDNET_ABI_VERSION 4
 
 int cidnet_abi_version(void);
 
@@ -112,13 +112,18 @@ int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_m
                             const float* Z, const float* slope, float* Y, float* Ypre, int B, int M,
                             int K, int zh, int zw, void* stream);
 /* Weight gradient dW[m][n] = sum_{b,p} dY[b][m][p] X[b][n][p]; per_sample: dW is (B,M,N) without
- * the batch sum.  dw_ld = row stride of dW (>= N).  Fixed-order reduction (reproducible). */
+ * the batch sum.  dw_ld = row stride of dW (>= N).  Fixed-order reduction (reproducible).
+ * flags: CIDNET_WGRAD_ACCUMULATE adds to dW instead of overwriting it; with fp32 operands the products run on the
+ * BF16 matrix cores as six exact bf16 cross products each (results within fp32 rounding, see cidnet_conv3x3_bf16x3)
+ * unless CIDNET_WGRAD_FP32_MFMA is set. */
+#define CIDNET_WGRAD_ACCUMULATE 1
+#define CIDNET_WGRAD_FP32_MFMA 2
 long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW);
 int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
-                      int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N, long HW,
+                      int per_sample, int flags, float* ws, long ws_floats, int B, int M, int N, long HW,
                       void* stream);
 int cidnet_pw_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, long dw_ld,
-                    int per_sample, int accumulate, float* ws, long ws_floats, int B, int M, int N,
+                    int per_sample, int flags, float* ws, long ws_floats, int B, int M, int N,
                     long HW, void* stream);
 
 /* ---- K5 / K8: depthwise 3x3 (zero pad) and the IEL gate  (net/LCA.py:14,16,53-55,62-65) --------

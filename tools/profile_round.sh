@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o b --output-format c
 echo "pmc fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o b --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-inference-leg --single-stream > $O/pmc_write.log 2>&1
 echo "pmc write done"
-python3 $R/tools/pmc_traffic.py $O/pmc_fetch/b_counter_collection.csv $O/pmc_write/b_counter_collection.csv $O/pmc_conv3_traffic.json conv3_kernel
+python3 $R/tools/pmc_family_traffic.py $O/pmc_fetch/b_counter_collection.csv $O/pmc_write/b_counter_collection.csv $O/pmc_traffic_by_family.json
 # keep the merged output small: drop the raw traces, keep the stats tables
 rm -f $O/stats*/b_kernel_trace.csv $O/pmc_*/b_kernel_trace.csv
 ls -la $O $O/stats2 | head -30
