@@ -28,6 +28,32 @@ constexpr int kMaxBlocks = 2048;
 // single largest VALU cost of these HBM-bound kernels.
 __device__ __forceinline__ float pow_fast(float base, float k) { return __builtin_amdgcn_exp2f(k * __builtin_amdgcn_logf(base)); }
 
+// atan2(y, x) in [-pi, pi] without the library call (which costs more than the rest of PHVIT's pixel together): the ratio
+// t = min(|x|, |y|) / max(|x|, |y|) by one IEEE division, an odd minimax polynomial of atan on [0, 1] (8 coefficients in
+// t^2, <= 3.5 ulp: the coefficients of SLEEF's atanf), then the octant.  What PHVIT needs beyond accuracy: for a tiny
+// negative angle (y < 0 << x) the reference's h = atan2(y, x) / (2 pi) % 1 rounds to exactly 1.0f and the pixel comes out
+// BLACK (hi == 6, net/HVI_transform.py:65-66,79-90).  There t^2 is below half an ulp of 1, the polynomial returns t itself,
+// i.e. the correctly rounded quotient |y| / |x| -- what atan2f returns for such arguments -- so the black pixels are the
+// reference's (tests/test_hvi_gpu.py: adversarial fixture, hi == 6 sets compared exactly).
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mx == 0.f ? 0.f : mn / mx;
+  const float t2 = t * t;
+  float u = 0.00282363896258175373077393f;
+  u = fmaf(u, t2, -0.0159569028764963150024414f);
+  u = fmaf(u, t2, 0.0425049886107444763183594f);
+  u = fmaf(u, t2, -0.0748900920152664184570312f);
+  u = fmaf(u, t2, 0.106347933411598205566406f);
+  u = fmaf(u, t2, -0.142027363181114196777344f);
+  u = fmaf(u, t2, 0.199926957488059997558594f);
+  u = fmaf(u, t2, -0.333331018686294555664062f);
+  float r = fmaf(t, t2 * u, t);
+  r = ay > ax ? 1.57079632679489661923f - r : r;
+  r = x < 0.f ? 3.14159265358979323846f - r : r;
+  return y < 0.f ? -r : r;
+}
+
 __device__ __forceinline__ void stage_trig(float2* T) {
   for (int i = threadIdx.x; i <= CIDNET_TRIG_N; i += blockDim.x) T[i] = g_trig_table[i];
   __syncthreads();
@@ -91,10 +117,11 @@ __global__ __launch_bounds__(kThreads) void hvit_fwd_kernel(const float* __restr
   __shared__ float2 T[CIDNET_TRIG_N + 1];
   stage_trig(T);
   const float k = kptr[0];
-  const long nq = (HW + 3) >> 2;
-  const long total = (long)B * nq;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const long b = it / nq, p = (it - b * nq) << 2;
+  const unsigned nq = (unsigned)((HW + 3) >> 2);            // pixel quads per plane; B * nq < 2^32 (checked by the launcher)
+  const unsigned total = (unsigned)B * nq;
+  for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const unsigned bq = it / nq;                                // 32-bit: a 64-bit division per pixel quad cost as much as the trigonometry
+    const long b = bq, p = (long)(it - bq * nq) << 2;
     const float* src = rgb + b * 3 * HW + p;
     float* dst = hvi + b * 3 * HW + p;
     const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
@@ -131,11 +158,12 @@ __global__ __launch_bounds__(kThreads) void hvit_bwd_kernel(const float* __restr
   __shared__ float red[kThreads / 64];
   stage_trig(T);
   const float k = kptr[0];
-  const long nq = (HW + 3) >> 2;
-  const long total = (long)B * nq;
+  const unsigned nq = (unsigned)((HW + 3) >> 2);            // pixel quads per plane; B * nq < 2^32 (checked by the launcher)
+  const unsigned total = (unsigned)B * nq;
   float gk_acc = 0.f;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const long b = it / nq, p = (it - b * nq) << 2;
+  for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const unsigned bq = it / nq;                                // 32-bit: a 64-bit division per pixel quad cost as much as the trigonometry
+    const long b = bq, p = (long)(it - bq * nq) << 2;
     const long off = b * 3 * HW + p;
     const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
     f32x4 r, g, bl, gh, gv, gi, or_, og, ob;
@@ -231,12 +259,11 @@ __device__ __forceinline__ PhvitPx phvit_px(float H0, float V0, float I0, float 
   o.V3 = fminf(fmaxf(o.V2, -1.f), 1.f);
   o.y = o.V3 + kEps;
   o.x = o.H3 + kEps;
-  float h = atan2f(o.y, o.x) / kTwoPi;
-  h = fmodf(h, 1.0f);
-  if (h != 0.f && h < 0.f) h += 1.0f;               // python-style h % 1 (may round to exactly 1.0)
+  float h = atan2_poly(o.y, o.x) / kTwoPi;           // |h| <= 0.5: fmod(h, 1) is h itself
+  if (h < 0.f) h += 1.0f;                           // python-style h % 1 (may round to exactly 1.0)
   o.h = h;
   o.u = (o.H3 * o.H3 + o.V3 * o.V3) + kEps;
-  o.s_pre = sqrtf(o.u);
+  o.s_pre = __builtin_amdgcn_sqrtf(o.u);            // u >= 1e-8: the hardware square root (1 ulp) is enough
   if (cfg.gated) o.s_pre = o.s_pre * cfg.alpha_s;
   o.s = fminf(fmaxf(o.s_pre, 0.f), 1.f);
   o.v = fminf(fmaxf(o.I1, 0.f), 1.f);
@@ -270,10 +297,11 @@ __global__ __launch_bounds__(kThreads) void phvit_fwd_kernel(const float* __rest
   __shared__ float2 T[CIDNET_TRIG_N + 1];
   stage_trig(T);
   const float k = kdev ? kdev[0] : cfg.k_host;
-  const long nq = (HW + 3) >> 2;
-  const long total = (long)B * nq;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const long b = it / nq, p = (it - b * nq) << 2;
+  const unsigned nq = (unsigned)((HW + 3) >> 2);            // pixel quads per plane; B * nq < 2^32 (checked by the launcher)
+  const unsigned total = (unsigned)B * nq;
+  for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const unsigned bq = it / nq;                                // 32-bit: a 64-bit division per pixel quad cost as much as the trigonometry
+    const long b = bq, p = (long)(it - bq * nq) << 2;
     const long off = b * 3 * HW + p;
     const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
     f32x4 a0, a1, a2, o0, o1, o2;
@@ -318,10 +346,11 @@ __global__ __launch_bounds__(kThreads) void phvit_bwd_kernel(const float* __rest
   __shared__ float2 T[CIDNET_TRIG_N + 1];
   stage_trig(T);
   const float k = kdev ? kdev[0] : cfg.k_host;
-  const long nq = (HW + 3) >> 2;
-  const long total = (long)B * nq;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const long b = it / nq, p = (it - b * nq) << 2;
+  const unsigned nq = (unsigned)((HW + 3) >> 2);            // pixel quads per plane; B * nq < 2^32 (checked by the launcher)
+  const unsigned total = (unsigned)B * nq;
+  for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const unsigned bq = it / nq;                                // 32-bit: a 64-bit division per pixel quad cost as much as the trigonometry
+    const long b = bq, p = (long)(it - bq * nq) << 2;
     const long off = b * 3 * HW + p;
     const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
     f32x4 a0, a1, a2, g0, g1, g2, d0, d1, d2;
@@ -411,6 +440,7 @@ extern "C" {
 int cidnet_hvit_fwd(const float* rgb, const float* density_k, float* hvi, uint8_t* branch_code, int B, int H, int W,
                     void* stream) {
   CIDNET_CHECK_ARG(rgb && density_k && hvi && B > 0 && H > 0 && W > 0);
+  if ((long)B * (((long)H * W + 3) >> 2) >= (1L << 32) - 65536L * 256) return CIDNET_ERR_SHAPE;   // 32-bit quad index in the kernels
   const long HW = (long)H * W;
   hipLaunchKernelGGL(hvit_fwd_kernel, dim3(grid_for(B, HW)), dim3(kThreads), 0, (hipStream_t)stream, rgb, density_k, hvi,
                      branch_code, B, HW);
@@ -423,6 +453,7 @@ long cidnet_hvit_bwd_ws_floats(void) { return kMaxBlocks; }
 int cidnet_hvit_bwd(const float* rgb, const float* density_k, const float* g_hvi, float* g_rgb, float* g_k, float* ws,
                     long ws_floats, int B, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(rgb && density_k && g_hvi && B > 0 && H > 0 && W > 0);
+  if ((long)B * (((long)H * W + 3) >> 2) >= (1L << 32) - 65536L * 256) return CIDNET_ERR_SHAPE;   // 32-bit quad index in the kernels
   CIDNET_CHECK_ARG(g_rgb || g_k);
   if (g_k && (!ws || ws_floats < kMaxBlocks)) return CIDNET_ERR_WS;
   const long HW = (long)H * W;
@@ -441,6 +472,7 @@ int cidnet_phvit_fwd(const float* hv, const float* iv, const float* hvi, const f
                      float alpha_s, int gated2, float alpha, float* rgb, uint8_t* sextant, int B, int H, int W,
                      void* stream) {
   CIDNET_CHECK_ARG(hvi && rgb && B > 0 && H > 0 && W > 0);
+  if ((long)B * (((long)H * W + 3) >> 2) >= (1L << 32) - 65536L * 256) return CIDNET_ERR_SHAPE;   // 32-bit quad index in the kernels
   CIDNET_CHECK_ARG((hv == nullptr) == (iv == nullptr));
   const long HW = (long)H * W;
   PhvitCfg cfg{k_host, gated, gated2, alpha_s, alpha};
@@ -454,6 +486,7 @@ int cidnet_phvit_bwd(const float* hv, const float* iv, const float* hvi, const f
                      float alpha_s, int gated2, float alpha, const float* g_rgb, float* g_hvi, float* g_hv, float* g_iv,
                      int B, int H, int W, void* stream) {
   CIDNET_CHECK_ARG(hvi && g_rgb && B > 0 && H > 0 && W > 0);
+  if ((long)B * (((long)H * W + 3) >> 2) >= (1L << 32) - 65536L * 256) return CIDNET_ERR_SHAPE;   // 32-bit quad index in the kernels
   CIDNET_CHECK_ARG((hv == nullptr) == (iv == nullptr));
   CIDNET_CHECK_ARG((g_hv == nullptr) == (g_iv == nullptr));
   CIDNET_CHECK_ARG(g_hvi || g_hv);
