@@ -321,7 +321,18 @@ def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, add
                    _p(y), M * H * W, B, M, K, H, W, _stream())
 
 
+# weight gradient of the same layers: csrc/conv3xw.hip (operands split once per staged tile, fragments by transposing LDS
+# reads); CIDNET_CONV3_WGRAD_BF16X3=0 selects the fp32-MFMA kernel (csrc/conv3.hip)
+CONV3_WGRAD_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_WGRAD_BF16X3", "1") == "1"}
+
+
 def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False):
+    if CONV3_WGRAD_BF16X3["on"] and not replicate and M > 4 and _raw("cidnet_conv3x3_wgrad_bf16x3_supported", M, N, H, W):
+        n = _raw("cidnet_conv3x3_wgrad_bf16x3_ws_floats", B, M, N, H, W)
+        ws = _ws(n, dy.device)
+        lib().call("cidnet_conv3x3_wgrad_bf16x3", _p(dy), M * H * W, _p(x), N * H * W, _p(dw), _p(ws), ws.numel(), B, M, N, H, W,
+                   _stream())
+        return
     n = _raw("cidnet_conv3x3_wgrad_ws_floats", B, M, N, H, W)
     ws = _ws(n, dy.device)
     lib().call("cidnet_conv3x3_wgrad", _p(dy), M * H * W, _p(x), N * H * W, int(replicate), _p(dw), _p(ws), ws.numel(), B, M,

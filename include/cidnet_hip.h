@@ -210,6 +210,13 @@ long cidnet_conv3x3_wgrad_ws_floats(int B, int M, int N, int H, int W);
 int cidnet_conv3x3_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int replicate,
                          float* dW, float* ws, long ws_floats, int B, int M, int N, int H, int W,
                          void* stream);
+/* The zero-pad weight gradient with split operands on the BF16 matrix cores (csrc/conv3xw.hip; arithmetic as
+ * cidnet_conv3x3_bf16x3, partial sums combined in fixed order: run-to-run identical).  dW (M, N, 3, 3) contiguous is
+ * overwritten.  _supported: N (input channels) a multiple of 36, W >= 4. */
+int cidnet_conv3x3_wgrad_bf16x3_supported(int M, int N, int H, int W);
+long cidnet_conv3x3_wgrad_bf16x3_ws_floats(int B, int M, int N, int H, int W);
+int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws,
+                                long ws_floats, int B, int M, int N, int H, int W, void* stream);
 /* Adds to gX (computed by the zero-pad data gradient) the taps that read replicated border pixels. */
 int cidnet_conv3x3_replicate_dgrad_fix(const float* gY, const float* Wt, float* gX, int B, int Co,
                                        int Ci, int H, int W, void* stream);

@@ -131,6 +131,36 @@ def test_conv3x3(dev, B, Ci, Co, H, W, rep):
         close(gw, wr.grad, what="wgrad")
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 36, 36, 16, 24), (1, 72, 144, 10, 15), (1, 144, 72, 50, 75), (3, 36, 72, 13, 37),
+                                         (1, 36, 100, 7, 5), (2, 72, 5, 9, 33), (1, 36, 36, 1, 4), (5, 36, 48, 4, 32),
+                                         (2, 36, 36, 70, 130)])
+def test_conv3x3_wgrad_bf16x3(dev, B, Ci, Co, H, W):
+    """csrc/conv3xw.hip against fp64 (ragged tiles, output-channel counts that are not whole 48-row chunks, planes smaller
+    than one tile), twice into NaN-filled outputs: every element written, run-to-run identical"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    assert ops.CONV3_WGRAD_BF16X3["on"] and lib().raw("cidnet_conv3x3_wgrad_bf16x3_supported")(Co, Ci, H, W)
+    x, gy = rnd(41, (B, Ci, H, W)), rnd(42, (B, Co, H, W))
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), gy.double(), padding=1)
+    xd, gyd = x.to(dev), gy.to(dev)
+    outs = []
+    for _ in range(2):
+        gw = torch.full((Co, Ci, 3, 3), float("nan"), device=dev)
+        ops.conv3x3_wgrad(gyd, xd, gw, B, Co, Ci, H, W)
+        outs.append(gw)
+    close(outs[0], ref.float(), what="wgrad bf16x3")
+    assert torch.equal(outs[0], outs[1])
+    # no less accurate than the fp32-MFMA kernel
+    ops.CONV3_WGRAD_BF16X3["on"] = False
+    try:
+        g32 = torch.empty_like(outs[0])
+        ops.conv3x3_wgrad(gyd, xd, g32, B, Co, Ci, H, W)
+    finally:
+        ops.CONV3_WGRAD_BF16X3["on"] = True
+    e3, e32 = (outs[0].double().cpu() - ref).abs().max().item(), (g32.double().cpu() - ref).abs().max().item()
+    assert e3 <= 2.0 * e32 + 1e-6 * ref.abs().max().item(), (e3, e32)
+
+
 @pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 36, 36, 16, 24), (1, 72, 36, 10, 15), (1, 12, 24, 9, 70), (1, 24, 12, 4, 4), (1, 144, 72, 25, 37)])
 def test_conv3x3_addend_and_down_skip(dev, B, Ci, Co, H, W):
     """cidnet_conv3x3_add == conv + addend bitwise (same kernel body, one more load in the epilogue), and the

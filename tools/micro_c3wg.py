@@ -15,14 +15,17 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 SHAPES = [(36, 36, 400, 600), (144, 72, 100, 150), (72, 36, 200, 300), (36, 36, 200, 300), (36, 72, 100, 150), (72, 144, 50, 75)]
 B = 8
-tot = gf_tot = 0.0
+tot = tot32 = gf_tot = 0.0
 for M, N, H, W in SHAPES:
     dy = torch.randn(B, M, H, W, device=dev); x = torch.randn(B, N, H, W, device=dev); dw = torch.empty(M, N, 3, 3, device=dev)
+    ops.CONV3_WGRAD_BF16X3["on"] = False
+    us32 = timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, B, M, N, H, W))
+    ops.CONV3_WGRAD_BF16X3["on"] = True
     us = timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, B, M, N, H, W))
     ref = torch.nn.grad.conv2d_weight(x[:1].double().cpu(), (M, N, 3, 3), dy[:1].double().cpu(), padding=1)
     dw1 = torch.empty(M, N, 3, 3, device=dev); ops.conv3x3_wgrad(dy[:1].contiguous(), x[:1].contiguous(), dw1, 1, M, N, H, W)
     err = (dw1.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     gf = 18.0 * M * N * H * W * B / 1e9
-    tot += 2 * us; gf_tot += 2 * gf
-    print(f"wgrad {M:3d}x{N:3d} @ {H}x{W}: {us:7.1f} us  {gf / us * 1e3:6.1f} TFLOP/s   rel err vs fp64 {err:.1e}")
-print(f"family per step (each shape twice): {tot / 1e3:.3f} ms, {gf_tot / tot * 1e3:.1f} TFLOP/s")
+    tot += 2 * us; tot32 += 2 * us32; gf_tot += 2 * gf
+    print(f"wgrad {M:3d}x{N:3d} @ {H}x{W}: {us:7.1f} us (fp32 MFMA {us32:7.1f})  {gf / us * 1e3:6.1f} TFLOP/s   rel err vs fp64 {err:.1e}")
+print(f"family per step (each shape twice): {tot / 1e3:.3f} ms (fp32 MFMA {tot32 / 1e3:.3f}), {gf_tot / tot * 1e3:.1f} TFLOP/s")
