@@ -1,22 +1,32 @@
 // Weight gradient of the dense 3x3 convolution (zero pad 1) with fp32 operands on the BF16 matrix cores: exact "bf16x3" split
-// products (arithmetic: conv3x.hip).  dW[m][ci][tap] = sum over pixels of dY[m][px] X[ci][px + tap]
+// products (arithmetic: conv3x.hip).  dW[co][ci][dy][dx] = sum over pixels of dY[co][y][x] X[ci][y + dy - 1][x + dx - 1]
 // (autograd of net/transformer_utils.py:39,58).
 //
 // k = pixels.  A first attempt (profiles/r03_e_...rejected.txt) split the operands in the k loop, once per fragment: 44 VALU
 // instructions per fragment that feeds only 18 MFMAs -- VALU-bound, slower than the fp32-MFMA kernel.  Here every element is
-// split ONCE, while its tile is staged into LDS exactly as conv3x.hip stages activations (pixel-major, channels innermost,
-// three bf16 levels), and the k loop reads fragments with ds_read_b64_tr_b16: the transposing LDS read hands a lane the four
-// consecutive PIXELS (k) of one channel (row / column of the product) out of a [pixel][channel] image.
+// split ONCE, while its tile is staged into LDS (pixel-major, channels innermost, three bf16 levels), and the k loop reads
+// fragments with ds_read_b64_tr_b16: the transposing LDS read hands a lane the four consecutive PIXELS (k) of one channel
+// out of a [pixel][channel] image.
 //
-//  * Block = 4 waves, persistent, two per CU; a tile = 4 rows x 32 pixels of dY (48 output channels of chunk mc, zero padded)
-//    and the same tile plus a 1-pixel halo of X (36 input channels of chunk nc): 3 x (6 x 34 x 72 B + 4 x 32 x 96 B) = 79 KB.
-//  * GEMM per tile row (32 pixels = one MFMA depth):  dW[48][324] += dY^T[48][32] * Xcol[32][324], columns c = 36 tap + ci
-//    (tap-major, so that the four consecutive columns a lane of the transposing read addresses are four consecutive channels
-//    of ONE tap: one 8-byte piece of the pixel at that tap's row / column offset).  324 columns = 21 tiles; wave w owns
-//    tiles w, w + 4, ...: 5 or 6 column tiles x 3 row tiles of accumulators (<= 72 registers) that live in registers for
-//    the WHOLE launch -- a block writes one slab at the end, a second kernel sums the slabs in fixed order.
-//  * Per tile row a wave reads 9 A fragments (3 row tiles x 3 levels, shared by all its column tiles) and 3 B fragments per
-//    column tile, two transposing reads each, one column tile ahead of the MFMAs (counted lgkmcnt), 18 MFMAs per column tile.
+//  * The product is arranged as  D[(dx, co)][(dy, ci)] += sum_x' dY[co][y][x' - dx + 1] X[ci][y + dy - 1][x']  with k = x'
+//    running over the 32 columns of a tile row: the horizontal tap shifts the dY operand, the vertical tap the X operand.
+//    For a chunk of 36 output x 36 input channels that is a 108 x 108 product = 7 x 7 MFMA tiles (49; rows = co and
+//    columns = (tap, ci) would take 3 x 21 = 63 for the same chunk).  Four consecutive rows (columns) of the product are
+//    four consecutive channels of ONE shift: one 8-byte piece of a staged pixel, which is what a lane of the transposing
+//    read addresses.
+//  * Block = 8 waves, persistent, one per CU; a tile = 4 rows x 32 pixels: X with a one-row halo above and below (6 x 32
+//    pixels), dY with a one-pixel halo left and right (4 x 34), 80-byte pixels (36 bf16 + pad: the four 16-lane groups of a
+//    transposing read then hit disjoint banks), three levels: 78,720 B per tile, TWO tile buffers.
+//  * Software pipeline per tile: a thread first issues the global loads of ITS share of the next tile into registers, then
+//    runs the MFMA loop of the current tile out of one buffer, then splits the loaded values and writes them to the other
+//    buffer; one barrier per tile.  (With the staging and the MFMA phase in sequence -- the first version of this kernel,
+//    two 4-wave blocks per CU -- the time was the SUM of the two phases, 420 us at 36->36 400x600, however the blocks
+//    were staggered: profiles/r03_f_conv3xw_ablation_first_version.txt.)
+//    The loads are inline assembly (see unit_load) and their results never live across the loop edge.
+//  * Wave w = (group w & 3, half w >> 2): the half selects tile rows {0,1} or {2,3} (a split of k), the group a
+//    near-rectangular 12 / 12 / 12 / 13-tile part of the 7 x 7 product, so the four SIMDs carry equal MFMA work.  The
+//    accumulators (<= 52 registers) live in registers for the WHOLE launch -- a wave writes one slab at the end, a second
+//    kernel sums the slabs in fixed order into dW's (co, ci, dy, dx) layout.
 // No packed-fp32 / SDWA instructions (hvi-cidnet_amd/build.py).
 #include "common.h"
 
@@ -28,28 +38,41 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
-constexpr int kWThreads = 256;
+constexpr int kWThreads = 512;
 constexpr int kWTH = 4, kWTW = 32;
-constexpr int kWMC = 48, kWNC = 36;                         // output channels / input channels per block
-constexpr int kWXRow = (kWTW + 2) * kWNC * 2;               // 2448 B per staged X row (34 pixels x 36 channels)
-constexpr int kWXLevel = (kWTH + 2) * kWXRow;               // 14688
-constexpr int kWYPix = kWMC * 2;                            // 96 B per staged dY pixel
-constexpr int kWYRow = kWTW * kWYPix;                       // 3072
-constexpr int kWYLevel = kWTH * kWYRow;                     // 12288
-constexpr int kWY0 = 3 * kWXLevel;                          // 44064
-constexpr int kWLds = kWY0 + 3 * kWYLevel;                  // 80928 B: two blocks per CU
-constexpr int kWCols = 9 * kWNC;                            // 324
-constexpr int kWNTiles = (kWCols + 15) / 16;                // 21
-constexpr int kWNTW = (kWNTiles + 3) / 4;                   // column tiles per wave (6; the last waves own 5)
-static_assert(2 * kWLds <= 160 * 1024, "two blocks per CU");
+constexpr int kWC = 36;                                     // channels per chunk on both sides
+constexpr int kWPix = 80;                                   // bytes per staged pixel and level
+constexpr int kWXRow = kWTW * kWPix;                        // 2560
+constexpr int kWXLevel = (kWTH + 2) * kWXRow;               // 15360
+constexpr int kWYCols = kWTW + 2;                           // 34
+constexpr int kWYRow = kWYCols * kWPix;                     // 2720
+constexpr int kWYLevel = kWTH * kWYRow;                     // 10880
+constexpr int kWY0 = 3 * kWXLevel;                          // 46080
+constexpr int kWBuf = kWY0 + 3 * kWYLevel;                  // 78720 B per tile buffer
+constexpr int kWLds = 2 * kWBuf;                            // 157440
+constexpr int kWDim = 3 * kWC;                              // 108 rows / columns of the chunk's product
+constexpr int kWT = (kWDim + 15) / 16;                      // 7 tiles per side
+constexpr int kWSlab = kWDim * kWDim;
+static_assert(kWLds <= 160 * 1024, "two tile buffers per CU");
+static_assert(2 * kWXLevel + (kWTH + 1) * kWXRow + 4 * kWPix < 65536, "ds offsets are 16-bit");
 
 struct W3Args {
   const float* dY; long dy_bs;
   const float* X; long x_bs;
-  float* slabs;                        // [pair][block][48][324] (columns tap-major)
+  float* slabs;                        // [pair][block][108][108]
   int B, M, N, H, W;
-  int tiles_x, tiles_y, mchunks, nchunks;
+  int tiles_x, tiles_y, nchunks;
+#ifdef CIDNET_DEBUG
+  int dbg;                             // timing study: 1 stage only the first tile, 2 no fragment reads / MFMAs,
+                                       // 8 loads without split / LDS writes (no switch may sit between a load and its wait)
+#endif
 };
+#ifdef CIDNET_DEBUG
+int g_w3_dbg = 0;
+#define W3_DBG(bit) (a.dbg & (bit))
+#else
+#define W3_DBG(bit) 0
+#endif
 
 // exact three-way split of two fp32 values into packed bf16 pairs (lo half = a, hi half = b), round to nearest even
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
@@ -75,187 +98,321 @@ __device__ __forceinline__ bf16x8 frag_of(u64 lo, u64 hi) {
   return __builtin_bit_cast(bf16x8, q);
 }
 
-// the six transposing reads of one column tile's B fragments (3 levels x 2 halves of the 32-pixel depth), tile row R
-template <int R>
-__device__ __forceinline__ void b_issue(u64 (&s)[6], unsigned addr) {
-  W3_TR(s[0], addr, R * kWXRow);
-  W3_TR(s[1], addr, R * kWXRow + 4 * kWNC * 2);
-  W3_TR(s[2], addr, R * kWXRow + kWXLevel);
-  W3_TR(s[3], addr, R * kWXRow + kWXLevel + 4 * kWNC * 2);
-  W3_TR(s[4], addr, R * kWXRow + 2 * kWXLevel);
-  W3_TR(s[5], addr, R * kWXRow + 2 * kWXLevel + 4 * kWNC * 2);
+// the six transposing reads of one fragment triple (3 levels x 2 halves of the 32-pixel depth) at byte offset OFF
+template <int OFF, int LEVEL>
+__device__ __forceinline__ void frag_issue(u64 (&s)[6], unsigned addr) {
+  W3_TR(s[0], addr, OFF);
+  W3_TR(s[1], addr, OFF + 4 * kWPix);
+  W3_TR(s[2], addr, OFF + LEVEL);
+  W3_TR(s[3], addr, OFF + LEVEL + 4 * kWPix);
+  W3_TR(s[4], addr, OFF + 2 * LEVEL);
+  W3_TR(s[5], addr, OFF + 2 * LEVEL + 4 * kWPix);
 }
 
-__global__ __launch_bounds__(kWThreads, 2) void conv3xw_kernel(W3Args a) {
+// One tile row R (of the wave's two) of a rectangular part of the product: row tiles RT0 .. RT0 + RTN - 1, column tiles
+// CT0 .. CT0 + CTN - 1, accumulators acc[ACC0 + ct * RTN + rt].  A fragments (dY) stay in registers for the row, B fragments
+// (X) are read one column tile ahead of their MFMAs.
+template <int RT0, int RTN, int CT0, int CTN, int ACC0, int R>
+__device__ __forceinline__ void part_row(f32x4 (&acc)[13], const unsigned (&aA)[kWT], const unsigned (&aB)[kWT]) {
+  u64 af[RTN][6];
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) frag_issue<R * kWYRow, kWYLevel>(af[rt], aA[RT0 + rt]);
+  u64 s0[6], s1[6];
+  frag_issue<R * kWXRow, kWXLevel>(s0, aB[CT0]);
+  bf16x8 a0[RTN], a1[RTN], a2[RTN];
+#pragma unroll
+  for (int ct = 0; ct < CTN; ++ct) {
+    u64 (&cs)[6] = (ct & 1) ? s1 : s0;
+    u64 (&nx)[6] = (ct & 1) ? s0 : s1;
+    if (ct + 1 < CTN) {
+      frag_issue<R * kWXRow, kWXLevel>(nx, aB[CT0 + (ct + 1 < CTN ? ct + 1 : ct)]);
+      W3_WAIT6(6, cs);
+    } else {
+      W3_WAIT6(0, cs);
+    }
+    if (ct == 0) {                                           // issued before s0: landed
+#pragma unroll
+      for (int rt = 0; rt < RTN; ++rt) {
+        asm volatile("" : "+v"(af[rt][0]), "+v"(af[rt][1]), "+v"(af[rt][2]), "+v"(af[rt][3]), "+v"(af[rt][4]), "+v"(af[rt][5]));
+        a0[rt] = frag_of(af[rt][0], af[rt][1]); a1[rt] = frag_of(af[rt][2], af[rt][3]); a2[rt] = frag_of(af[rt][4], af[rt][5]);
+      }
+    }
+    const bf16x8 b0 = frag_of(cs[0], cs[1]), b1 = frag_of(cs[2], cs[3]), b2 = frag_of(cs[4], cs[5]);
+    f32x4* c = &acc[ACC0 + ct * RTN];
+    // small terms first
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[rt], b0, c[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b1, c[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b2, c[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b0, c[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b1, c[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b0, c[rt], 0, 0, 0);
+  }
+}
+
+// the four groups' parts of the 7 x 7 product: 4x3, 4x3, 3x4 and 3x3 + 4x1 tiles
+template <int R>
+__device__ __forceinline__ void group_row(int grp, f32x4 (&acc)[13], const unsigned (&aA)[kWT], const unsigned (&aB)[kWT]) {
+  if (grp == 0) {
+    part_row<0, 4, 0, 3, 0, R>(acc, aA, aB);
+  } else if (grp == 1) {
+    part_row<0, 4, 3, 3, 0, R>(acc, aA, aB);
+  } else if (grp == 2) {
+    part_row<4, 3, 0, 4, 0, R>(acc, aA, aB);
+  } else {
+    part_row<4, 3, 4, 3, 0, R>(acc, aA, aB);
+    part_row<0, 4, 6, 1, 9, R>(acc, aA, aB);
+  }
+}
+
+template <int RT0, int RTN, int CT0, int CTN, int ACC0>
+__device__ __forceinline__ void part_store(const f32x4 (&acc)[13], float* slab, int n, int g) {
+#pragma unroll
+  for (int ct = 0; ct < CTN; ++ct) {
+    const int c = 16 * (CT0 + ct) + n;
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * (RT0 + rt) + 4 * g + reg;
+        if (r < kWDim && c < kWDim) slab[r * kWDim + c] = acc[ACC0 + ct * RTN + rt][reg];
+      }
+  }
+}
+
+// one staging unit = 4 channels x 4 consecutive pixels of one tile row: X rows y0 - 1 .. y0 + 4, columns x0 .. x0 + 31
+// (8 quads); dY rows y0 .. y0 + 3, columns x0 - 4 .. x0 + 35 (10 quads, of which columns x0 - 1 .. x0 + 32 are staged)
+constexpr int kWXUnits = (kWTH + 2) * (kWC / 4) * 8;        // 432
+constexpr int kWYUnits = kWTH * (kWC / 4) * 10;             // 360
+constexpr int kWRounds = (kWXUnits + kWYUnits + kWThreads - 1) / kWThreads;   // 2
+struct Unit {
+  int live, isx, ry, cg, col;          // col: first pixel of the quad relative to x0
+};
+__device__ __forceinline__ Unit unit_of(int u) {
+  Unit t;
+  t.live = u < kWXUnits + kWYUnits;
+  t.isx = u < kWXUnits;
+  const int uu = t.isx ? u : u - kWXUnits;
+  const int nq = t.isx ? 8 : 10;
+  const int qq = uu % nq, r = uu / nq;
+  t.cg = r % (kWC / 4);
+  t.ry = r / (kWC / 4);
+  t.col = t.isx ? 4 * qq : 4 * qq - 4;
+  return t;
+}
+
+// The global loads of a unit are inline assembly: compiler-generated loads make the waitcnt pass put "s_waitcnt vmcnt(0)"
+// in front of the MFMA loop's (inline-assembly) LDS reads and between the two rounds -- the loads then do not stay in flight
+// behind the MFMAs.  Every load is an unconditional dwordx4 from a clamped, always valid address; what the unit must not
+// see is repaired after the wait (unit_fix): fix = 4 the quad lies outside the image (zero), fix = 1..3 the quad straddles
+// the right edge and was loaded from column W - 4 instead (shift by fix pixels; only when W is not a multiple of 4).
+__device__ __forceinline__ void unit_load(const Unit& t, const float* xb, const float* yb, int y0, int x0, int H, int W, long HW,
+                                          f32x4 (&q)[4], int& fix) {
+  const int gy = t.isx ? y0 - 1 + t.ry : y0 + t.ry;
+  const int gx0 = x0 + t.col;                                // a multiple of 4: never straddles the left edge
+  const bool out = gy < 0 || gy >= H || gx0 < 0 || gx0 >= W;
+  const bool part = !out && gx0 + 3 >= W;
+  fix = out ? 4 : part ? gx0 - (W - 4) : 0;
+  const int sx = out ? 0 : part ? W - 4 : gx0, sy = out ? 0 : gy;
+  const float* src = (t.isx ? xb : yb) + (long)(4 * t.cg) * HW + (long)sy * W + sx;
+  if (t.live) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[c]) : "v"(src + (long)c * HW));
+  }
+}
+
+// all loads issued so far have landed: every later use of the two rounds' values depends on this statement
+__device__ __forceinline__ void units_wait(f32x4 (&q0)[4], f32x4 (&q1)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]));
+}
+
+__device__ __forceinline__ void unit_write(const Unit& t, const f32x4 (&q)[4], int fix, unsigned char* buf, int dbg = 0) {
+  if (!t.live) return;
+  float v[16];                                               // [channel][pixel]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { v[4 * c] = q[c][0]; v[4 * c + 1] = q[c][1]; v[4 * c + 2] = q[c][2]; v[4 * c + 3] = q[c][3]; }
+  if (fix != 0) {                                            // image border: rare
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float e1 = v[4 * c + 1], e2 = v[4 * c + 2], e3 = v[4 * c + 3];
+      v[4 * c] = fix == 1 ? e1 : fix == 2 ? e2 : fix == 3 ? e3 : 0.f;
+      v[4 * c + 1] = fix == 1 ? e2 : fix == 2 ? e3 : 0.f;
+      v[4 * c + 2] = fix == 1 ? e3 : 0.f;
+      v[4 * c + 3] = 0.f;
+    }
+  }
+#ifdef CIDNET_DEBUG
+  if (dbg & 8) {                                             // timing study: consume the loads with one store
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += v[i];
+    *reinterpret_cast<float*>(buf + kWBuf - 4096 + (threadIdx.x & 63) * 4) = sum;
+    return;
+  }
+#endif
+  unsigned char* base = t.isx ? buf + t.ry * kWXRow + t.col * kWPix + t.cg * 8
+                              : buf + kWY0 + t.ry * kWYRow + (t.col + 1) * kWPix + t.cg * 8;
+  const int lvl = t.isx ? kWXLevel : kWYLevel;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int lc = t.isx ? t.col + j : t.col + j + 1;        // column inside the staged tile
+    if (lc < 0 || lc >= (t.isx ? kWTW : kWYCols)) continue;
+    unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+    split3_pair(v[j], v[4 + j], p0a, p1a, p2a);
+    split3_pair(v[8 + j], v[12 + j], p0b, p1b, p2b);
+    unsigned char* dst = base + j * kWPix;
+    *reinterpret_cast<uint2*>(dst) = uint2{p0a, p0b};
+    *reinterpret_cast<uint2*>(dst + lvl) = uint2{p1a, p1b};
+    *reinterpret_cast<uint2*>(dst + 2 * lvl) = uint2{p2a, p2b};
+  }
+}
+
+__global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave & 3, kh = wave >> 2;
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const int H = a.H, W = a.W, M = a.M;
+  const int H = a.H, W = a.W;
   const long HW = (long)H * W;
   const int mc = blockIdx.y / a.nchunks, nc = blockIdx.y - mc * a.nchunks;
 
-  // this lane's transposing-read addresses: pixel 8 g + q of a tile row (+ 4 for the second half of the depth)
-  const unsigned aA = (unsigned)(kWY0 + (8 * g + q) * kWYPix + 8 * p);          // + 32 mt + 4 * 96 h + level + row
-  unsigned aB[kWNTW];
+  // this lane's transposing-read addresses in tile buffer 0: k = pixel 8 g + q of a tile row (+ 4 for the second half)
+  unsigned aA[kWT], aB[kWT];
 #pragma unroll
-  for (int j = 0; j < kWNTW; ++j) {
-    int c = (wave + 4 * j) * 16 + 4 * p;
-    if (c >= kWCols) c = 0;                                  // past the last column: any valid piece (never stored)
-    const int tap = c / kWNC, ci = c - tap * kWNC;
-    const int dy = tap / 3, dx = tap - 3 * dy;
-    aB[j] = (unsigned)(dy * kWXRow + (8 * g + q + dx) * (kWNC * 2) + ci * 2);   // + 4 * 72 h + level + row
+  for (int t = 0; t < kWT; ++t) {
+    int r4 = 16 * t + 4 * p;
+    if (r4 >= kWDim) r4 = 0;                                 // past the last row / column: any valid piece (never stored)
+    const int sh = r4 / kWC, ch = r4 - sh * kWC;
+    aA[t] = (unsigned)(kWY0 + 2 * kh * kWYRow + (8 * g + q + 2 - sh) * kWPix + ch * 2);   // dY column x' - dx + 1 (halo at 0)
+    aB[t] = (unsigned)((2 * kh + sh) * kWXRow + (8 * g + q) * kWPix + ch * 2);            // X row y + dy - 1 (halo at 0)
   }
 
-  f32x4 acc[kWNTW][3];
+  f32x4 acc[13];
 #pragma unroll
-  for (int j = 0; j < kWNTW; ++j)
+  for (int i = 0; i < 13; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Unit un[kWRounds];
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < kWRounds; ++r) un[r] = unit_of(tid + r * kWThreads);
 
   const unsigned tiles_per_img = a.tiles_x * a.tiles_y;
   const unsigned ntiles = (unsigned)a.B * tiles_per_img;
-  // the second half of the grid starts late so that the two blocks of a CU alternate staging and MFMA phases (conv3x.hip)
-  if (blockIdx.x >= (gridDim.x >> 1) && gridDim.x > 1) {
-    __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(64);
-  }
+  const float* xc = a.X + (long)nc * kWC * HW;
+  const float* yc = a.dY + (long)mc * kWC * HW;
+  static_assert(kWRounds == 2, "units_wait takes two rounds");
+  f32x4 pq[kWRounds][4];
+  int fix[kWRounds];
 
-  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  auto load_tile = [&](unsigned tile) {
     const int b = (int)(tile / tiles_per_img), tr = (int)(tile - (unsigned)b * tiles_per_img);
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-    const int y0 = ty * kWTH, x0 = tx * kWTW;
-    __syncthreads();                                         // the previous tile's fragment reads are done
-    // ---- stage: unit = (row, 4-channel group, pixel quad): X with its halo (quads from x0 - 4), then dY ----
-    {
-      const float* xb = a.X + (long)b * a.x_bs + (long)nc * kWNC * HW;
-      const float* yb = a.dY + (long)b * a.dy_bs;
-      constexpr int XQ = 10, XCG = kWNC / 4, XU = (kWTH + 2) * XCG * XQ;          // 540
-      constexpr int YQ = 8, YCG = kWMC / 4, YU = kWTH * YCG * YQ;                 // 384
-      constexpr int ROUNDS = (XU + YU + kWThreads - 1) / kWThreads;
-#pragma unroll 2
-      for (int rnd = 0; rnd < ROUNDS; ++rnd) {
-        const int u = tid + rnd * kWThreads;
-        if (u >= XU + YU) continue;
-        const bool isx = u < XU;
-        const int uu = isx ? u : u - XU;
-        const int nq = isx ? XQ : YQ, ncg = isx ? XCG : YCG;
-        const int qq = uu % nq, t = uu / nq;
-        const int cg = t % ncg, ry = t / ncg;
-        const int gy = isx ? y0 - 1 + ry : y0 + ry;
-        const int gx0 = isx ? x0 - 4 + 4 * qq : x0 + 4 * qq;
-        const int ch0 = isx ? 4 * cg : mc * kWMC + 4 * cg;                        // first of the unit's four channels
-        const int nch = isx ? 4 : min(4, M - ch0);                                // live channels (dY rows past M are zero)
-        const bool row_in = gy >= 0 && gy < H;
-        const float* src = (isx ? xb : yb) + (long)ch0 * HW + (long)(row_in ? gy : 0) * W;
-        float v[4][4];                                       // [channel][pixel]
-        if (row_in && gx0 >= 0 && gx0 + 3 < W && nch == 4) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const f32x4 w4 = load4u(src + (long)c * HW + gx0);
-            v[c][0] = w4[0]; v[c][1] = w4[1]; v[c][2] = w4[2]; v[c][3] = w4[3];
-          }
-        } else {
+    for (int r = 0; r < kWRounds; ++r)
+      unit_load(un[r], xc + (long)b * a.x_bs, yc + (long)b * a.dy_bs, ty * kWTH, tx * kWTW, H, W, HW, pq[r], fix[r]);
+  };
+  auto write_tile = [&](unsigned char* buf) {
+    units_wait(pq[0], pq[1]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int gx = gx0 + j;
-              v[c][j] = (row_in && gx >= 0 && gx < W && c < nch) ? src[(long)c * HW + gx] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int lc = isx ? 4 * qq + j - 3 : 4 * qq + j;  // column inside the staged tile
-          if (lc < 0 || lc >= (isx ? kWTW + 2 : kWTW)) continue;
-          unsigned p0a, p1a, p2a, p0b, p1b, p2b;
-          split3_pair(v[0][j], v[1][j], p0a, p1a, p2a);
-          split3_pair(v[2][j], v[3][j], p0b, p1b, p2b);
-          unsigned char* dst = isx ? xs + ry * kWXRow + lc * (kWNC * 2) + cg * 8 : xs + kWY0 + ry * kWYRow + lc * kWYPix + cg * 8;
-          const int lvl = isx ? kWXLevel : kWYLevel;
-          *reinterpret_cast<uint2*>(dst) = uint2{p0a, p0b};
-          *reinterpret_cast<uint2*>(dst + lvl) = uint2{p1a, p1b};
-          *reinterpret_cast<uint2*>(dst + 2 * lvl) = uint2{p2a, p2b};
-        }
-      }
-    }
-    __syncthreads();
+    for (int r = 0; r < kWRounds; ++r) unit_write(un[r], pq[r], fix[r], buf, W3_DBG(8));
+  };
 
-    // ---- k loop: one 32-pixel tile row per step ----
-#define W3_ROW(R)                                                                                                    \
-    {                                                                                                                \
-      u64 af[3][6];                                                                                                  \
-      _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) {                                                             \
-        W3_TR(af[mt][0], aA, R * kWYRow + 32 * mt);                                                                  \
-        W3_TR(af[mt][1], aA, R * kWYRow + 32 * mt + 4 * kWYPix);                                                     \
-        W3_TR(af[mt][2], aA, R * kWYRow + 32 * mt + kWYLevel);                                                       \
-        W3_TR(af[mt][3], aA, R * kWYRow + 32 * mt + kWYLevel + 4 * kWYPix);                                          \
-        W3_TR(af[mt][4], aA, R * kWYRow + 32 * mt + 2 * kWYLevel);                                                   \
-        W3_TR(af[mt][5], aA, R * kWYRow + 32 * mt + 2 * kWYLevel + 4 * kWYPix);                                      \
-      }                                                                                                              \
-      u64 s0[6], s1[6];                                                                                              \
-      b_issue<R>(s0, aB[0]);                                                                                         \
-      bf16x8 a0[3], a1[3], a2[3];                                                                                    \
-      _Pragma("unroll") for (int j = 0; j < kWNTW; ++j) {                                                            \
-        if (wave + 4 * j >= kWNTiles) break;                 /* wave-uniform */                                      \
-        u64 (&cs)[6] = (j & 1) ? s1 : s0;                                                                            \
-        u64 (&nx)[6] = (j & 1) ? s0 : s1;                                                                            \
-        const bool more = j + 1 < kWNTW && wave + 4 * (j + 1) < kWNTiles;                                            \
-        if (more) { b_issue<R>(nx, aB[j + 1 < kWNTW ? j + 1 : j]); W3_WAIT6(6, cs); } else { W3_WAIT6(0, cs); }      \
-        if (j == 0) {                                         /* the A reads were issued before s0: they have landed */ \
-          _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) {                                                         \
-            asm volatile("" : "+v"(af[mt][0]), "+v"(af[mt][1]), "+v"(af[mt][2]), "+v"(af[mt][3]), "+v"(af[mt][4]), "+v"(af[mt][5])); \
-            a0[mt] = frag_of(af[mt][0], af[mt][1]); a1[mt] = frag_of(af[mt][2], af[mt][3]); a2[mt] = frag_of(af[mt][4], af[mt][5]); \
-          }                                                                                                          \
-        }                                                                                                            \
-        const bf16x8 b0 = frag_of(cs[0], cs[1]), b1 = frag_of(cs[2], cs[3]), b2 = frag_of(cs[4], cs[5]);            \
-        _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b0, acc[j][mt], 0, 0, 0); \
-        _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[j][mt], 0, 0, 0); \
-        _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b2, acc[j][mt], 0, 0, 0); \
-        _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b0, acc[j][mt], 0, 0, 0); \
-        _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b1, acc[j][mt], 0, 0, 0); \
-        _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b0, acc[j][mt], 0, 0, 0); \
-      }                                                                                                              \
+  unsigned tile = blockIdx.x;                                // the launcher gives every block at least one tile
+  load_tile(tile);
+  write_tile(xs);
+  __syncthreads();
+
+  // The loaded values are defined and consumed inside ONE iteration, by unconditional statements: values in flight
+  // across the loop edge (an earlier version let half of the waves run a tile ahead) made the compiler copy the load
+  // destination registers at the loop header BEFORE the wait -- it cannot know that the assembly's results are pending.
+  const unsigned G = gridDim.x;
+  unsigned cur = 0;                                          // byte offset of the buffer the MFMA loop reads
+  for (; tile < ntiles; tile += G) {
+    const bool has_next = tile + G < ntiles;
+    const bool stage = has_next && !W3_DBG(1);
+    load_tile(has_next ? tile + G : tile);                   // in flight during the MFMA loop (last tile: loaded again, unused)
+    if (!W3_DBG(2)) {
+      group_row<0>(grp, acc, aA, aB);
+      group_row<1>(grp, acc, aA, aB);
     }
-    W3_ROW(0) W3_ROW(1) W3_ROW(2) W3_ROW(3)
-#undef W3_ROW
+    units_wait(pq[0], pq[1]);
+    if (stage) {
+#pragma unroll
+      for (int r = 0; r < kWRounds; ++r) unit_write(un[r], pq[r], fix[r], xs + (cur ? 0 : kWBuf), W3_DBG(8));
+      const unsigned d = cur ? (unsigned)-kWBuf : (unsigned)kWBuf;
+#pragma unroll
+      for (int t = 0; t < kWT; ++t) { aA[t] += d; aB[t] += d; }
+      cur = cur ? 0u : (unsigned)kWBuf;
+    }
+    if (has_next) __syncthreads();
   }
 
-  // ---- this block's partial dW of the (mc, nc) chunk pair: lane (n, g) holds rows 4 g + reg, column n of every tile ----
-  float* slab = a.slabs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (kWMC * kWCols);
+  // ---- the block's partial of the (mc, nc) chunk pair: the two k halves are added through LDS (fixed order), then lane
+  // (n, g) of the first half's waves stores rows 4 g + reg, column n of every tile of its group ----
+  __syncthreads();                                           // the last tile's fragment reads are done: LDS is free
+  f32x4* xch = reinterpret_cast<f32x4*>(xs) + (grp * 13) * 64 + lane;
+  if (kh == 1) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xch[i * 64] = acc[i];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) acc[i] += xch[i * 64];
+  float* slab = a.slabs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * kWSlab;
   const int n = lane & 15;
-#pragma unroll
-  for (int j = 0; j < kWNTW; ++j) {
-    const int c = (wave + 4 * j) * 16 + n;
-    if (wave + 4 * j >= kWNTiles || c >= kWCols) continue;
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) slab[(mt * 16 + 4 * g + reg) * kWCols + c] = acc[j][mt][reg];
+  if (grp == 0) {
+    part_store<0, 4, 0, 3, 0>(acc, slab, n, g);
+  } else if (grp == 1) {
+    part_store<0, 4, 3, 3, 0>(acc, slab, n, g);
+  } else if (grp == 2) {
+    part_store<4, 3, 0, 4, 0>(acc, slab, n, g);
+  } else {
+    part_store<4, 3, 4, 3, 0>(acc, slab, n, g);
+    part_store<0, 4, 6, 1, 9>(acc, slab, n, g);
   }
 }
 
-// dW[m][ci][tap] = sum over the blocks of the chunk pair (mc, nc) of slab[m - 48 mc][36 tap + ci - 36 nc]; fixed order
-__global__ __launch_bounds__(256) void conv3xw_reduce_kernel(const float* __restrict__ slabs, int nblk, int M, int N, int nchunks,
+// dW[co][ci][dy][dx] = sum over the nslab slabs of the chunk pair (co / 36, ci / 36) of slab[36 dx + co % 36][36 dy + ci % 36].
+// A block sums 32 consecutive slab elements (coalesced reads): thread (e, sub) adds slabs sub, sub + 8, ..., the eight
+// partial sums are then added in fixed order.
+__global__ __launch_bounds__(256) void conv3xw_reduce_kernel(const float* __restrict__ slabs, int nslab, int npairs, int N, int nchunks,
                                                              float* __restrict__ dW) {
-  const int i = blockIdx.x * 256 + threadIdx.x;               // element of dW in memory order
-  if (i >= M * N * 9) return;
-  const int m = i / (N * 9), rem = i - m * (N * 9), ci = rem / 9, tap = rem - ci * 9;
-  const int mc = m / kWMC, nc = ci / kWNC;
-  const float* s = slabs + ((long)(mc * nchunks + nc) * nblk) * (kWMC * kWCols) + (m - mc * kWMC) * kWCols + tap * kWNC + (ci - nc * kWNC);
+  __shared__ float part[8][32];
+  const int e = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int E = blockIdx.x * 32 + e;
+  const bool live = E < npairs * kWSlab;
+  const int pair = live ? E / kWSlab : 0, j = live ? E - pair * kWSlab : 0;
+  const float* s = slabs + (long)pair * nslab * kWSlab + j;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nblk; k += 4) {
-    t0 += s[(long)k * (kWMC * kWCols)]; t1 += s[(long)(k + 1) * (kWMC * kWCols)];
-    t2 += s[(long)(k + 2) * (kWMC * kWCols)]; t3 += s[(long)(k + 3) * (kWMC * kWCols)];
+  int k = sub;
+  for (; k + 24 < nslab; k += 32) {
+    t0 += s[(long)k * kWSlab]; t1 += s[(long)(k + 8) * kWSlab];
+    t2 += s[(long)(k + 16) * kWSlab]; t3 += s[(long)(k + 24) * kWSlab];
   }
-  for (; k < nblk; ++k) t0 += s[(long)k * (kWMC * kWCols)];
-  dW[i] = (t0 + t1) + (t2 + t3);
+  for (; k < nslab; k += 8) t0 += s[(long)k * kWSlab];
+  part[sub][e] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (sub != 0 || !live) return;
+  float t = part[0][e];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) t += part[i][e];
+  const int r = j / kWDim, c = j - r * kWDim;
+  const int dx = r / kWC, co = r - dx * kWC, dy = c / kWC, ci = c - dy * kWC;
+  const int mc = pair / nchunks, nc = pair - mc * nchunks;
+  dW[((long)(mc * kWC + co) * N + nc * kWC + ci) * 9 + dy * 3 + dx] = t;
 }
 
 inline int w3_blocks_per_pair(int B, int M, int N, int H, int W) {
-  const int pairs = ((M + kWMC - 1) / kWMC) * (N / kWNC);
+  const int pairs = (M / kWC) * (N / kWC);
   const long ntiles = (long)B * ((W + kWTW - 1) / kWTW) * ((H + kWTH - 1) / kWTH);
-  long nb = 512 / pairs;                                      // persistent: two resident blocks per CU in total
+  long nb = 256 / pairs;                                      // persistent: one resident block per CU in total
   if (nb < 1) nb = 1;
   if (nb > ntiles) nb = ntiles;
   return (int)nb;
@@ -268,13 +425,15 @@ using namespace cidnet;
 
 extern "C" {
 
-/* input channels in whole 36-channel chunks (CIDNet's 36 / 72 / 144); planes at least one pixel quad wide */
-int cidnet_conv3x3_wgrad_bf16x3_supported(int M, int N, int H, int W) { return M >= 1 && N >= 36 && N % 36 == 0 && H >= 1 && W >= 4; }
+/* whole 36-channel chunks on both sides (CIDNet's 36 / 72 / 144); planes at least one pixel quad wide */
+int cidnet_conv3x3_wgrad_bf16x3_supported(int M, int N, int H, int W) {
+  return M >= kWC && M % kWC == 0 && N >= kWC && N % kWC == 0 && H >= 1 && W >= 4;
+}
 
 long cidnet_conv3x3_wgrad_bf16x3_ws_floats(int B, int M, int N, int H, int W) {
   if (!cidnet_conv3x3_wgrad_bf16x3_supported(M, N, H, W)) return 0;
-  const long pairs = (long)((M + kWMC - 1) / kWMC) * (N / kWNC);
-  return pairs * w3_blocks_per_pair(B, M, N, H, W) * (kWMC * kWCols);
+  const long pairs = (long)(M / kWC) * (N / kWC);
+  return pairs * w3_blocks_per_pair(B, M, N, H, W) * kWSlab;
 }
 
 int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws, long ws_floats,
@@ -282,7 +441,10 @@ int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, lon
   CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && H > 0 && W > 0);
   if (!cidnet_conv3x3_wgrad_bf16x3_supported(M, N, H, W)) return CIDNET_ERR_SHAPE;
   if (ws_floats < cidnet_conv3x3_wgrad_bf16x3_ws_floats(B, M, N, H, W)) return CIDNET_ERR_WS;
-  W3Args a{dY, dy_bs, X, x_bs, ws, B, M, N, H, W, (W + kWTW - 1) / kWTW, (H + kWTH - 1) / kWTH, (M + kWMC - 1) / kWMC, N / kWNC};
+  W3Args a{dY, dy_bs, X, x_bs, ws, B, M, N, H, W, (W + kWTW - 1) / kWTW, (H + kWTH - 1) / kWTH, N / kWC};
+#ifdef CIDNET_DEBUG
+  a.dbg = g_w3_dbg;
+#endif
   const int nblk = w3_blocks_per_pair(B, M, N, H, W);
   static bool attr = false;                                   // idempotent: raises the kernel's dynamic-LDS limit once
   if (!attr) {
@@ -290,12 +452,16 @@ int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, lon
     attr = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3xw_kernel, dim3((unsigned)nblk, (unsigned)(a.mchunks * a.nchunks)), dim3(kWThreads), kWLds, s, a);
+  hipLaunchKernelGGL(conv3xw_kernel, dim3((unsigned)nblk, (unsigned)((M / kWC) * (N / kWC))), dim3(kWThreads), kWLds, s, a);
   CIDNET_LAUNCH_STATUS();
-  const int ne = M * N * 9;
-  hipLaunchKernelGGL(conv3xw_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, ws, nblk, M, N, a.nchunks, dW);
+  const int npairs = (M / kWC) * (N / kWC);
+  hipLaunchKernelGGL(conv3xw_reduce_kernel, dim3((unsigned)((npairs * kWSlab + 31) / 32)), dim3(256), 0, s, ws, nblk, npairs, N, a.nchunks, dW);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
+
+#ifdef CIDNET_DEBUG
+void cidnet_debug_c3xw_flags(int flags) { g_w3_dbg = flags; }
+#endif
 
 }  // extern "C"

@@ -217,6 +217,10 @@ int cidnet_conv3x3_wgrad_bf16x3_supported(int M, int N, int H, int W);
 long cidnet_conv3x3_wgrad_bf16x3_ws_floats(int B, int M, int N, int H, int W);
 int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws,
                                 long ws_floats, int B, int M, int N, int H, int W, void* stream);
+#ifdef CIDNET_DEBUG
+/* timing-study switches for cidnet_conv3x3_wgrad_bf16x3 (1 stage only a block's first tile, 2 no fragment reads / MFMAs) */
+void cidnet_debug_c3xw_flags(int flags);
+#endif
 /* Adds to gX (computed by the zero-pad data gradient) the taps that read replicated border pixels. */
 int cidnet_conv3x3_replicate_dgrad_fix(const float* gY, const float* Wt, float* gX, int B, int Co,
                                        int Ci, int H, int W, void* stream);

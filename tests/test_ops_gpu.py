@@ -132,11 +132,11 @@ def test_conv3x3(dev, B, Ci, Co, H, W, rep):
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 36, 36, 16, 24), (1, 72, 144, 10, 15), (1, 144, 72, 50, 75), (3, 36, 72, 13, 37),
-                                         (1, 36, 100, 7, 5), (2, 72, 5, 9, 33), (1, 36, 36, 1, 4), (5, 36, 48, 4, 32),
-                                         (2, 36, 36, 70, 130)])
+                                         (1, 36, 108, 7, 5), (2, 72, 36, 9, 33), (1, 36, 36, 1, 4), (5, 36, 72, 4, 32),
+                                         (2, 36, 36, 70, 130), (1, 36, 36, 3, 31), (9, 36, 36, 5, 64)])
 def test_conv3x3_wgrad_bf16x3(dev, B, Ci, Co, H, W):
-    """csrc/conv3xw.hip against fp64 (ragged tiles, output-channel counts that are not whole 48-row chunks, planes smaller
-    than one tile), twice into NaN-filled outputs: every element written, run-to-run identical"""
+    """csrc/conv3xw.hip against fp64 (ragged tiles, several 36-channel chunks on either side, planes smaller than one tile,
+    blocks with one and with many tiles), twice into NaN-filled outputs: every element written, run-to-run identical"""
     from hvi_cidnet_amd import ops
     from hvi_cidnet_amd._lib import lib
     assert ops.CONV3_WGRAD_BF16X3["on"] and lib().raw("cidnet_conv3x3_wgrad_bf16x3_supported")(Co, Ci, H, W)
