@@ -22,7 +22,8 @@
 //    buffer; one barrier per tile.  (With the staging and the MFMA phase in sequence -- the first version of this kernel,
 //    two 4-wave blocks per CU -- the time was the SUM of the two phases, 420 us at 36->36 400x600, however the blocks
 //    were staggered: profiles/r03_f_conv3xw_ablation_first_version.txt.)
-//    The loads are inline assembly (see unit_load) and their results never live across the loop edge.
+//    The loads are inline assembly (see unit_load); half of the waves split / write BEFORE their MFMA loop, one tile
+//    further ahead (see the period loop in the kernel).
 //  * Wave w = (group w & 3, half w >> 2): the half selects tile rows {0,1} or {2,3} (a split of k), the group a
 //    near-rectangular 12 / 12 / 12 / 13-tile part of the 7 x 7 product, so the four SIMDs carry equal MFMA work.  The
 //    accumulators (<= 52 registers) live in registers for the WHOLE launch -- a wave writes one slab at the end, a second
@@ -38,7 +39,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
-constexpr int kWThreads = 512;
+constexpr int kWMmaWaves = 8, kWStageWaves = 4;              // consumer / producer waves of a block
+constexpr int kWThreads = 64 * (kWMmaWaves + kWStageWaves);
 constexpr int kWTH = 4, kWTW = 32;
 constexpr int kWC = 36;                                     // channels per chunk on both sides
 constexpr int kWPix = 80;                                   // bytes per staged pixel and level
@@ -155,14 +157,16 @@ __device__ __forceinline__ void part_row(f32x4 (&acc)[13], const unsigned (&aA)[
   }
 }
 
-// the four groups' parts of the 7 x 7 product: 4x3, 4x3, 3x4 and 3x3 + 4x1 tiles
-template <int R>
-__device__ __forceinline__ void group_row(int grp, f32x4 (&acc)[13], const unsigned (&aA)[kWT], const unsigned (&aB)[kWT]) {
-  if (grp == 0) {
+// the four groups' parts of the 7 x 7 product: 4x3, 4x3, 3x4 and 3x3 + 4x1 tiles.  The group is a template parameter of the
+// whole MFMA-wave loop: with the four variants in one loop body the register allocator shuffled the accumulators between
+// the variants' assignments and spilled.
+template <int GRP, int R>
+__device__ __forceinline__ void group_row(f32x4 (&acc)[13], const unsigned (&aA)[kWT], const unsigned (&aB)[kWT]) {
+  if (GRP == 0) {
     part_row<0, 4, 0, 3, 0, R>(acc, aA, aB);
-  } else if (grp == 1) {
+  } else if (GRP == 1) {
     part_row<0, 4, 3, 3, 0, R>(acc, aA, aB);
-  } else if (grp == 2) {
+  } else if (GRP == 2) {
     part_row<4, 3, 0, 4, 0, R>(acc, aA, aB);
   } else {
     part_row<4, 3, 4, 3, 0, R>(acc, aA, aB);
@@ -189,7 +193,8 @@ __device__ __forceinline__ void part_store(const f32x4 (&acc)[13], float* slab, 
 // (8 quads); dY rows y0 .. y0 + 3, columns x0 - 4 .. x0 + 35 (10 quads, of which columns x0 - 1 .. x0 + 32 are staged)
 constexpr int kWXUnits = (kWTH + 2) * (kWC / 4) * 8;        // 432
 constexpr int kWYUnits = kWTH * (kWC / 4) * 10;             // 360
-constexpr int kWRounds = (kWXUnits + kWYUnits + kWThreads - 1) / kWThreads;   // 2
+constexpr int kWStageThreads = 64 * kWStageWaves;
+constexpr int kWRounds = (kWXUnits + kWYUnits + kWStageThreads - 1) / kWStageThreads;   // 4
 struct Unit {
   int live, isx, ry, cg, col;          // col: first pixel of the quad relative to x0
 };
@@ -226,10 +231,12 @@ __device__ __forceinline__ void unit_load(const Unit& t, const float* xb, const 
   }
 }
 
-// all loads issued so far have landed: every later use of the two rounds' values depends on this statement
-__device__ __forceinline__ void units_wait(f32x4 (&q0)[4], f32x4 (&q1)[4]) {
+// all loads issued so far have landed: every later use of the rounds' values depends on this statement
+__device__ __forceinline__ void units_wait(f32x4 (&q)[kWRounds][4]) {
+  static_assert(kWRounds == 4, "one operand per loaded register quad");
   asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]));
+               : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]),
+                 "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[2][3]), "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]), "+v"(q[3][3]));
 }
 
 __device__ __forceinline__ void unit_write(const Unit& t, const f32x4 (&q)[4], int fix, unsigned char* buf, int dbg = 0) {
@@ -273,90 +280,42 @@ __device__ __forceinline__ void unit_write(const Unit& t, const f32x4 (&q)[4], i
   }
 }
 
-__global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave & 3, kh = wave >> 2;
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const int H = a.H, W = a.W;
-  const long HW = (long)H * W;
-  const int mc = blockIdx.y / a.nchunks, nc = blockIdx.y - mc * a.nchunks;
-
+template <int GRP>
+__device__ __forceinline__ void mma_waves(const W3Args& a, unsigned char* xs, int kh, int lane, int nt) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
   // this lane's transposing-read addresses in tile buffer 0: k = pixel 8 g + q of a tile row (+ 4 for the second half)
   unsigned aA[kWT], aB[kWT];
 #pragma unroll
   for (int t = 0; t < kWT; ++t) {
-    int r4 = 16 * t + 4 * p;
+    int r4 = 16 * t + 4 * p4;
     if (r4 >= kWDim) r4 = 0;                                 // past the last row / column: any valid piece (never stored)
     const int sh = r4 / kWC, ch = r4 - sh * kWC;
     aA[t] = (unsigned)(kWY0 + 2 * kh * kWYRow + (8 * g + q + 2 - sh) * kWPix + ch * 2);   // dY column x' - dx + 1 (halo at 0)
     aB[t] = (unsigned)((2 * kh + sh) * kWXRow + (8 * g + q) * kWPix + ch * 2);            // X row y + dy - 1 (halo at 0)
   }
-
   f32x4 acc[13];
 #pragma unroll
   for (int i = 0; i < 13; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  Unit un[kWRounds];
-#pragma unroll
-  for (int r = 0; r < kWRounds; ++r) un[r] = unit_of(tid + r * kWThreads);
-
-  const unsigned tiles_per_img = a.tiles_x * a.tiles_y;
-  const unsigned ntiles = (unsigned)a.B * tiles_per_img;
-  const float* xc = a.X + (long)nc * kWC * HW;
-  const float* yc = a.dY + (long)mc * kWC * HW;
-  static_assert(kWRounds == 2, "units_wait takes two rounds");
-  f32x4 pq[kWRounds][4];
-  int fix[kWRounds];
-
-  auto load_tile = [&](unsigned tile) {
-    const int b = (int)(tile / tiles_per_img), tr = (int)(tile - (unsigned)b * tiles_per_img);
-    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-#pragma unroll
-    for (int r = 0; r < kWRounds; ++r)
-      unit_load(un[r], xc + (long)b * a.x_bs, yc + (long)b * a.dy_bs, ty * kWTH, tx * kWTW, H, W, HW, pq[r], fix[r]);
-  };
-  auto write_tile = [&](unsigned char* buf) {
-    units_wait(pq[0], pq[1]);
-#pragma unroll
-    for (int r = 0; r < kWRounds; ++r) unit_write(un[r], pq[r], fix[r], buf, W3_DBG(8));
-  };
-
-  unsigned tile = blockIdx.x;                                // the launcher gives every block at least one tile
-  load_tile(tile);
-  write_tile(xs);
+  __syncthreads();                                           // periods -2 and -1: tile 0 is being staged
   __syncthreads();
-
-  // The loaded values are defined and consumed inside ONE iteration, by unconditional statements: values in flight
-  // across the loop edge (an earlier version let half of the waves run a tile ahead) made the compiler copy the load
-  // destination registers at the loop header BEFORE the wait -- it cannot know that the assembly's results are pending.
-  const unsigned G = gridDim.x;
-  unsigned cur = 0;                                          // byte offset of the buffer the MFMA loop reads
-  for (; tile < ntiles; tile += G) {
-    const bool has_next = tile + G < ntiles;
-    const bool stage = has_next && !W3_DBG(1);
-    load_tile(has_next ? tile + G : tile);                   // in flight during the MFMA loop (last tile: loaded again, unused)
+  for (int p = 0; p < nt; ++p) {
     if (!W3_DBG(2)) {
-      group_row<0>(grp, acc, aA, aB);
-      group_row<1>(grp, acc, aA, aB);
+      group_row<GRP, 0>(acc, aA, aB);
+      group_row<GRP, 1>(acc, aA, aB);
     }
-    units_wait(pq[0], pq[1]);
-    if (stage) {
-#pragma unroll
-      for (int r = 0; r < kWRounds; ++r) unit_write(un[r], pq[r], fix[r], xs + (cur ? 0 : kWBuf), W3_DBG(8));
-      const unsigned d = cur ? (unsigned)-kWBuf : (unsigned)kWBuf;
+    if (!W3_DBG(1)) {                                        // the next tile is in the other buffer
+      const unsigned d = (p & 1) ? (unsigned)-kWBuf : (unsigned)kWBuf;
 #pragma unroll
       for (int t = 0; t < kWT; ++t) { aA[t] += d; aB[t] += d; }
-      cur = cur ? 0u : (unsigned)kWBuf;
     }
-    if (has_next) __syncthreads();
+    __syncthreads();
   }
 
   // ---- the block's partial of the (mc, nc) chunk pair: the two k halves are added through LDS (fixed order), then lane
   // (n, g) of the first half's waves stores rows 4 g + reg, column n of every tile of its group ----
-  __syncthreads();                                           // the last tile's fragment reads are done: LDS is free
-  f32x4* xch = reinterpret_cast<f32x4*>(xs) + (grp * 13) * 64 + lane;
+  __syncthreads();                                           // (kept for symmetry with the staging waves: LDS is free)
+  f32x4* xch = reinterpret_cast<f32x4*>(xs) + (GRP * 13) * 64 + lane;
   if (kh == 1) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) xch[i * 64] = acc[i];
@@ -367,16 +326,73 @@ __global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
   for (int i = 0; i < 13; ++i) acc[i] += xch[i * 64];
   float* slab = a.slabs + ((long)blockIdx.y * gridDim.x + blockIdx.x) * kWSlab;
   const int n = lane & 15;
-  if (grp == 0) {
+  if (GRP == 0) {
     part_store<0, 4, 0, 3, 0>(acc, slab, n, g);
-  } else if (grp == 1) {
+  } else if (GRP == 1) {
     part_store<0, 4, 3, 3, 0>(acc, slab, n, g);
-  } else if (grp == 2) {
+  } else if (GRP == 2) {
     part_store<4, 3, 0, 4, 0>(acc, slab, n, g);
   } else {
     part_store<4, 3, 4, 3, 0>(acc, slab, n, g);
     part_store<0, 4, 6, 1, 9>(acc, slab, n, g);
   }
+}
+
+__global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+  const int mc = blockIdx.y / a.nchunks, nc = blockIdx.y - mc * a.nchunks;
+  const unsigned tiles_per_img = a.tiles_x * a.tiles_y;
+  const unsigned ntiles = (unsigned)a.B * tiles_per_img;
+  const unsigned G = gridDim.x;
+  const int nt = (int)((ntiles - blockIdx.x + G - 1) / G);   // this block's tiles j = 0 .. nt - 1: tile blockIdx.x + j G, buffer j & 1
+
+  // Periods p = -2 .. nt - 1, one barrier each.  In period p the MFMA waves run the MFMA loop of tile p; the staging waves
+  // wait for the loads they issued in period p - 1, split / write tile p + 1 into the other buffer, and issue the loads of
+  // tile p + 2, which then have a whole period to land.  The two roles are separate loops (disjoint register live ranges)
+  // with the same number of barriers.
+  if (wave >= kWMmaWaves) {
+    // There is ONE static load site and its wait is unconditional, so the values pending across the loop edge have a
+    // single definition: no copy of a load destination register before its wait (tests/test_abi.py checks the code object).
+    Unit un[kWRounds];
+    f32x4 pq[kWRounds][4];
+    int fix[kWRounds];
+    const float* xc = a.X + (long)nc * kWC * HW;
+    const float* yc = a.dY + (long)mc * kWC * HW;
+#pragma unroll
+    for (int r = 0; r < kWRounds; ++r) un[r] = unit_of((tid - 64 * kWMmaWaves) + r * kWStageThreads);
+    for (int p = -2; p < nt; ++p) {
+      units_wait(pq);
+      const bool wr = p + 1 >= 0 && p + 1 < nt && !(W3_DBG(1) && p + 1 > 0);
+      if (wr) {
+        unsigned char* wbuf = xs + (((p + 1) & 1) && !W3_DBG(1) ? kWBuf : 0);
+#pragma unroll
+        for (int r = 0; r < kWRounds; ++r) unit_write(un[r], pq[r], fix[r], wbuf, W3_DBG(8));
+      }
+      int jl = p + 2;
+      jl = jl >= nt ? nt - 1 : jl;                           // past the block's range: a valid tile, loaded and not used
+      const unsigned tile = blockIdx.x + (unsigned)jl * G;
+      const int b = (int)(tile / tiles_per_img), tr = (int)(tile - (unsigned)b * tiles_per_img);
+      const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+#pragma unroll
+      for (int r = 0; r < kWRounds; ++r)
+        unit_load(un[r], xc + (long)b * a.x_bs, yc + (long)b * a.dy_bs, ty * kWTH, tx * kWTW, H, W, HW, pq[r], fix[r]);
+      __syncthreads();
+    }
+    units_wait(pq);                                          // the last (unused) loads
+    __syncthreads();                                         // the two barriers of the MFMA waves' epilogue
+    __syncthreads();
+    return;
+  }
+
+  const int grp = wave & 3, kh = wave >> 2;
+  if (grp == 0) mma_waves<0>(a, xs, kh, lane, nt);
+  else if (grp == 1) mma_waves<1>(a, xs, kh, lane, nt);
+  else if (grp == 2) mma_waves<2>(a, xs, kh, lane, nt);
+  else mma_waves<3>(a, xs, kh, lane, nt);
 }
 
 // dW[co][ci][dy][dx] = sum over the nslab slabs of the chunk pair (co / 36, ci / 36) of slab[36 dx + co % 36][36 dy + ci % 36].
