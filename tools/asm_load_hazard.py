@@ -45,7 +45,7 @@ def _regs(ins):
 
 
 def check(text, kernel="conv3xw_kernel"):
-    """-> (number of inline-assembly loads, list of offending instructions)"""
+    """-> (number of global_load_dwordx4, list of instructions that touch a register with a pending load)"""
     seq = _instructions(text, kernel)
     # basic blocks
     blocks, cur, labels = [], [], {}
@@ -73,39 +73,54 @@ def check(text, kernel="conv3xw_kernel"):
         if not last.startswith(("s_branch", "s_endpgm")) and i + 1 < len(blocks):
             s.append(i + 1)
         succ.append([t for t in s if t < len(blocks)])
+    # vmcnt model: vector-memory operations complete in order; `s_waitcnt vmcnt(N)` returns when at most N are outstanding.
+    # State = registers pending at block entry (a set: everything inherited is older than the block's own operations) plus
+    # the block's own operations in order (destination sets; empty for stores).  vmcnt(N) with at least N own operations
+    # retires everything inherited and all but the last N own ones; with fewer it keeps the inherited set (conservative).
+    # Compiler-generated loads are modelled the same way as the inline-assembly ones: their waits are correct by
+    # construction, and they decide how long the assembly loads between them stay pending.
     pend_in = [set() for _ in blocks]
-    bad, loads = {}, 0
+    bad = {}
     work = list(range(len(blocks)))
-    first = True
+    mem = re.compile(r"^(global|buffer|scratch|flat)_(load|store|atomic)")
     while work:
         i = work.pop(0)
-        pending = set(pend_in[i])
+        inherited, own = set(pend_in[i]), []
         for ins in blocks[i]:
-            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", ins)
-            if m:
-                if pending and (_regs(ins.split(",", 1)[1]) & pending):      # its address registers
+            pending = inherited.union(*own) if own else inherited
+            if mem.match(ins):
+                ops = ins.split(None, 1)[1] if " " in ins else ""
+                first = ops.split(",", 1)[0]
+                rest = ops.split(",", 1)[1] if "," in ops else ""
+                is_load = "_load" in ins.split()[0] or ("_atomic" in ins.split()[0] and " glc" in ins)
+                touched = _regs(rest) | (_regs(first) if not is_load else set())     # addresses / store data are read now
+                if pending and (touched & pending):
                     bad[(i, ins)] = True
-                pending |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                own.append(_regs(first) if is_load else set())
                 continue
-            if re.search(r"s_waitcnt.*vmcnt\(0\)", ins):
-                pending = set()
+            m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", ins)
+            if m:
+                nleft = int(m.group(1))
+                if len(own) >= nleft:
+                    inherited = set()
+                    own = own[len(own) - nleft:] if nleft else []
                 continue
             if pending and (_regs(ins) & pending):
                 bad[(i, ins)] = True
+        out = inherited.union(*own) if own else inherited
         for t in succ[i]:
-            if not pending <= pend_in[t]:
-                pend_in[t] |= pending
+            if not out <= pend_in[t]:
+                pend_in[t] |= out
                 if t not in work:
                     work.append(t)
-    for b in blocks:
-        loads += sum(1 for ins in b if ins.startswith("global_load_dwordx4"))
+    loads = sum(1 for b in blocks for ins in b if ins.startswith("global_load_dwordx4"))
     return loads, [ins for (_, ins) in bad]
 
 
 if __name__ == "__main__":
     text = open(sys.argv[1]).read()
     n, bad = check(text, sys.argv[2] if len(sys.argv) > 2 else "conv3xw_kernel")
-    print(f"{n} inline-assembly loads, {len(bad)} instructions touch a register with a pending load")
+    print(f"{n} dwordx4 loads, {len(bad)} instructions touch a register with a pending load")
     for ins in bad[:8]:
         print("   ", ins)
     sys.exit(1 if bad or n == 0 else 0)
