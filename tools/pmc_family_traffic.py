@@ -39,8 +39,8 @@ for name, needles in FAMILIES.items():
                      "raw_bytes": int((fetch + write) * 1024), "hbm_bytes": int((2 * fetch + write) * 1024),
                      "avg_hbm_bytes_per_launch": int((2 * fetch + write) * 1024 / launches)}
 def short(k):
-    k = k.split("(")[0]
-    return k[-90:]
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("cidnet::", "")
+    return k.split("(")[0][:90]
 
 
 top = sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0.0)))[:30]
