@@ -256,7 +256,10 @@ def main():
         dist.init_process_group("nccl")
 
     import hvi_cidnet_amd as P
-    from hvi_cidnet_amd.dp import DataParallelTrainer
+    from hvi_cidnet_amd.dp import DataParallelTrainer, pin_rank_to_cpus
+    cpus = pin_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # per-rank CPU slice (N > 1 only)
+    if cpus is not None:
+        print(f"[bench] rank {rank}: pinned to {len(cpus)} CPUs ({cpus[0]}..{cpus[-1]})", file=sys.stderr)
     P.set_storage_dtype(a.dtype)
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)

@@ -22,7 +22,7 @@ def test_shipped_library_has_no_debug_state():
     (cidnet_debug_*) exist only in -DCIDNET_DEBUG builds, never in the in-tree library"""
     from hvi_cidnet_amd import _lib
     dll = ctypes.CDLL(_lib.LIB_PATH)
-    for name in ("cidnet_debug_pw_flags", "cidnet_debug_dw_rows", "cidnet_debug_c3_flags", "cidnet_debug_c3_phases"):
+    for name in ("cidnet_debug_pw_flags", "cidnet_debug_dw_rows", "cidnet_debug_c3_flags", "cidnet_debug_c3_phases", "cidnet_debug_c3xw_flags"):
         assert not hasattr(dll, name), f"{name} exported by the production library"
     assert not any(n.startswith("cidnet_debug") for n in _lib.parse_header())
 

@@ -234,3 +234,43 @@ def test_dp_layout_mismatch_between_ranks_raises():
         assert p.exitcode == 0
     assert "layout differs between ranks" in res[0], res
     assert "layout differs between ranks" in res[1], res
+
+
+def test_rank_cpu_sets_partition_the_job():
+    """per-rank CPU affinity (dp.pin_rank_to_cpus): the local ranks' slices are disjoint, contiguous, cover every CPU and
+    differ by at most one in size; with fewer CPUs than ranks every rank still gets one"""
+    from hvi_cidnet_amd.dp import rank_cpu_set
+    for cpus, world in ((list(range(8)), 2), (list(range(3, 131, 2)), 8), (list(range(16)), 3), ([5], 1)):
+        parts = [rank_cpu_set(cpus, r, world) for r in range(world)]
+        assert sorted(c for p in parts for c in p) == sorted(cpus)
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        for p in parts:
+            assert p == sorted(cpus)[sorted(cpus).index(p[0]):sorted(cpus).index(p[0]) + len(p)]
+    assert [rank_cpu_set([0, 1], r, 4) for r in range(4)] == [[0], [1], [0], [1]]
+
+
+def _affinity_worker(rank, world, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from hvi_cidnet_amd.dp import pin_rank_to_cpus
+    before = sorted(os.sched_getaffinity(0))
+    mine = pin_rank_to_cpus(rank, world)
+    q.put((rank, before, mine, sorted(os.sched_getaffinity(0)), torch.get_num_threads()))
+
+
+@pytest.mark.timeout(120)
+def test_pin_rank_to_cpus_two_processes():
+    if not hasattr(os, "sched_setaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs two usable CPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_affinity_worker, args=(r, 2, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=100) for _ in ps)
+    for p in ps:
+        p.join(30)
+    (_, before0, mine0, after0, nt0), (_, before1, mine1, after1, nt1) = got
+    assert before0 == before1 and mine0 == after0 and mine1 == after1
+    assert not set(mine0) & set(mine1) and sorted(mine0 + mine1) == before0
+    assert 1 <= nt0 <= len(mine0) and 1 <= nt1 <= len(mine1)
