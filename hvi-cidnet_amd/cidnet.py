@@ -160,6 +160,8 @@ class CIDNet(nn.Module, _HubMixin):
     # module's norm still runs on its own branch's stream (the in-place summing of LayerNorm parameter gradients relies on
     # that), and the forward needs no extra synchronisation: t1 / t2 are views of t.
     chain_lca_inputs = True
+    # the two norms that read the same LCA input as ONE pass (ops.LayerNormDualFn): x read once in the forward, once in the backward
+    dual_norms = True
 
     def _lca_pair(self, I_blk, HV_blk, i, hv):
         if not (self.chain_lca_inputs and torch.is_grad_enabled() and (i.requires_grad or hv.requires_grad)):
@@ -176,9 +178,19 @@ class CIDNet(nn.Module, _HubMixin):
                 return f()
             with torch.cuda.stream(side):
                 return f()
-        (hv_nhv, hv1), (i_nhv, i1) = on_side(lambda: (HV_blk.norm.forward_res(hv), HV_blk.norm.forward_res(i)))
-        i_ni, i2 = I_blk.norm.forward_res(i1)
-        hv_ni, hv2 = I_blk.norm.forward_res(hv1)
+        if self.dual_norms and ops.ln_dual_supported(i) and ops.ln_dual_supported(hv):
+            # one pass per input: its own block's x-norm (+ residual hand-over) and the partner block's y-norm of it
+            hv_nhv, hv_ni, hv2 = on_side(lambda: HV_blk.norm.forward_dual(hv, I_blk.norm))
+            i_ni, i_nhv, i2 = I_blk.norm.forward_dual(i, HV_blk.norm)
+            if two:                              # each branch now consumes a tensor the other branch's stream produced
+                main.wait_stream(side)
+                side.wait_stream(main)
+                hv_ni.record_stream(main)
+                i_nhv.record_stream(side)
+        else:
+            (hv_nhv, hv1), (i_nhv, i1) = on_side(lambda: (HV_blk.norm.forward_res(hv), HV_blk.norm.forward_res(i)))
+            i_ni, i2 = I_blk.norm.forward_res(i1)
+            hv_ni, hv2 = I_blk.norm.forward_res(hv1)
         out_hv = on_side(lambda: HV_blk.body(hv_nhv, i_nhv, hv2))
         out_i = I_blk.body(i_ni, hv_ni, i2)
         if two:

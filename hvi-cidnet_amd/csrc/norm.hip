@@ -72,9 +72,13 @@ template <> __device__ __forceinline__ f32x4 vrsqrt_eps<4>(f32x4 v, float invC, 
 }
 
 // ---- register-resident column kernels (HW % VEC == 0) -----------------------------------------
+// w2 / bias2 / y2 (all or none): a second LayerNorm MODULE applied to the same tensor (the x-norm of one LCA block and the
+// y-norm of its partner, net/LCA.py:79,91): the normalised value is the same, so the tensor is read once and written twice
 template <int C, int VEC>
 __global__ __launch_bounds__(kThreads) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                              const float* __restrict__ w2, const float* __restrict__ bias2,
+                                                              float* __restrict__ y2,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int B,
                                                               long HW, float eps) {
   typedef typename Vec<VEC>::T V;
@@ -98,6 +102,11 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_reg_kernel(const float* __res
     float* yb = y + b * C * HW + p;
 #pragma unroll
     for (int c = 0; c < C; ++c) Vec<VEC>::st(yb + (long)c * HW, (col[c] - u) * rs * w[c] + bias[c]);
+    if (y2) {
+      float* y2b = y2 + b * C * HW + p;
+#pragma unroll
+      for (int c = 0; c < C; ++c) Vec<VEC>::st(y2b + (long)c * HW, (col[c] - u) * rs * w2[c] + bias2[c]);
+    }
     if (mean) { Vec<VEC>::st(mean + b * HW + p, u); Vec<VEC>::st(rstd + b * HW + p, rs); }
   }
 }
@@ -192,23 +201,29 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_kernel(const float* __re
 // lane per pixel column the extra 2C accumulators do not fit (264 / 360 VGPRs when tried), so FOUR adjacent lanes
 // share a pixel vector and each keeps C/4 channels: x-hat, g*w and the accumulators are CQ*VEC + CQ*VEC + 2*CQ
 // registers, and the two channel sums are combined across the quad.  part: [gridDim.x][2C] = (dw | db) per block.
-template <int CQ, int VEC, int LPP>      // LPP lanes per pixel vector (4 or 8), CQ = C / LPP channels per lane
+// DUAL: two LayerNorm modules were applied to the same x (ln_fwd_reg_kernel's second output): the input gradient is linear
+// in g = gy*w, so gx = LN'(gy*w + gy2*w2) in one pass over x; the second module's dw / db partials follow the first's in
+// `part` (4 C floats per block).
+template <int CQ, int VEC, int LPP, bool DUAL = false>      // LPP lanes per pixel vector (4 or 8), CQ = C / LPP channels per lane
 __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                     const float* __restrict__ gy, const float* __restrict__ mean,
+                                                                     const float* __restrict__ gy, const float* __restrict__ w2,
+                                                                     const float* __restrict__ gy2, const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, const float* __restrict__ addend,
                                                                      float* __restrict__ gx, float* __restrict__ part, int B, long HW) {
   typedef typename Vec<VEC>::T V;
   constexpr int C = LPP * CQ;
   constexpr int LOG = LPP == 8 ? 3 : 2;
-  __shared__ float red[(kThreads / 64) * LPP * 2 * CQ];
+  constexpr int NP = DUAL ? 2 : 1;
+  __shared__ float red[(kThreads / 64) * LPP * 2 * CQ * NP];
   const long nq = HW / VEC;
   const long total = (long)B * nq;
   const float invC = 1.0f / (float)C;
   const int q = threadIdx.x & (LPP - 1);
   const float* wq = w + q * CQ;
-  float aw[CQ], ab[CQ];
+  const float* wq2 = DUAL ? w2 + q * CQ : nullptr;
+  float aw[CQ], ab[CQ], aw2[DUAL ? CQ : 1], ab2[DUAL ? CQ : 1];
 #pragma unroll
-  for (int c = 0; c < CQ; ++c) { aw[c] = 0.f; ab[c] = 0.f; }
+  for (int c = 0; c < CQ; ++c) { aw[c] = 0.f; ab[c] = 0.f; if (DUAL) { aw2[c] = 0.f; ab2[c] = 0.f; } }
   for (long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> LOG; it < total; it += ((long)gridDim.x * blockDim.x) >> LOG) {
     const long b = it / nq, p = (it - b * nq) * VEC;
     const long base = (b * C + (long)q * CQ) * HW + p;
@@ -226,6 +241,12 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float
       aw[c] += Vec<VEC>::hsum(g * xh[c]);
       ab[c] += Vec<VEC>::hsum(g);
       gw[c] = g * wq[c];
+      if (DUAL) {
+        const V g2 = Vec<VEC>::ld(gy2 + base + (long)c * HW);
+        aw2[c] += Vec<VEC>::hsum(g2 * xh[c]);
+        ab2[c] += Vec<VEC>::hsum(g2);
+        gw[c] += g2 * wq2[c];
+      }
       s1 += gw[c];
       s2 += gw[c] * xh[c];
     }
@@ -240,36 +261,44 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float
   }
   // lanes with equal q: butterfly over the other lane bits, then the four waves through LDS (fixed order)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WS = LPP * 2 * CQ;                          // floats per wave and module in red
 #pragma unroll
   for (int c = 0; c < CQ; ++c) {
     float a = aw[c], d = ab[c];
 #pragma unroll
     for (int m = LPP; m < 64; m <<= 1) { a += __shfl_xor(a, m); d += __shfl_xor(d, m); }
     if (lane < LPP) { red[(wave * LPP + q) * 2 * CQ + c] = a; red[(wave * LPP + q) * 2 * CQ + CQ + c] = d; }
+    if (DUAL) {
+      float a2 = aw2[c], d2 = ab2[c];
+#pragma unroll
+      for (int m = LPP; m < 64; m <<= 1) { a2 += __shfl_xor(a2, m); d2 += __shfl_xor(d2, m); }
+      if (lane < LPP) { red[4 * WS + (wave * LPP + q) * 2 * CQ + c] = a2; red[4 * WS + (wave * LPP + q) * 2 * CQ + CQ + c] = d2; }
+    }
   }
   __syncthreads();
-  constexpr int WS = LPP * 2 * CQ;                          // floats per wave in red
-  for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
-    const int which = i / C, ch = i - which * C;           // 0: dw, 1: db
+  for (int i = threadIdx.x; i < 2 * C * NP; i += kThreads) {
+    const int mod = i / (2 * C), r = i - mod * 2 * C;
+    const int which = r / C, ch = r - which * C;           // 0: dw, 1: db
     const int qq = ch / CQ, k = ch - qq * CQ;
-    const int o = qq * 2 * CQ + which * CQ + k;
-    part[(long)blockIdx.x * 2 * C + i] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
+    const int o = mod * 4 * WS + qq * 2 * CQ + which * CQ + k;
+    part[(long)blockIdx.x * 2 * C * NP + i] = (red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o]);
   }
 }
 
 // gw[c], gb[c] = sum over blocks of part[blk][c], part[blk][C + c]: 8 outputs per block, 32 lanes per output
 // accumulate != 0: gw / gb += the sums (a LayerNorm module applied several times per step adds up its uses' gradients
 // in place, in backward order, instead of through separate autograd accumulation launches)
+// `part` rows are `stride` floats apart and this module's 2 C values start at `off` (dual backward: stride 4 C, off 0 / 2 C)
 __global__ __launch_bounds__(256) void ln_wb2_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ gw,
-                                                            float* __restrict__ gb, int accumulate) {
+                                                            float* __restrict__ gb, int accumulate, int stride, int off) {
   __shared__ float fold[32][9];
   const int ex = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int i = blockIdx.x * 8 + ex;
   float t0 = 0.f, t1 = 0.f;
   if (i < 2 * C) {
     int k = sl;
-    for (; k + 32 < nblk; k += 64) { t0 += part[(long)k * 2 * C + i]; t1 += part[(long)(k + 32) * 2 * C + i]; }
-    if (k < nblk) t0 += part[(long)k * 2 * C + i];
+    for (; k + 32 < nblk; k += 64) { t0 += part[(long)k * stride + off + i]; t1 += part[(long)(k + 32) * stride + off + i]; }
+    if (k < nblk) t0 += part[(long)k * stride + off + i];
   }
   fold[sl][ex] = t0 + t1;
   __syncthreads();
@@ -418,13 +447,13 @@ int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, flo
   // launch at 200x300, i.e. one read burst followed by one write burst: 26.8 -> 23.7 us (tools/micro_ln.py)
   if (C == 36)
     hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
-                       mean, rstd, B, HW, eps);
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, mean, rstd, B, HW, eps);
   else if (C == 72)                                           // one pixel per lane, as for C = 36: 21 -> 17 us at 100x150
     hipLaunchKernelGGL((ln_fwd_reg_kernel<72, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
-                       mean, rstd, B, HW, eps);
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, mean, rstd, B, HW, eps);
   else if (C == 144)
     hipLaunchKernelGGL((ln_fwd_reg_kernel<144, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
-                       mean, rstd, B, HW, eps);
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, mean, rstd, B, HW, eps);
   else
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, s, x, weight, bias, y, mean,
                        rstd, B, C, HW, eps);
@@ -454,19 +483,19 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
     const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 4 : (HW % 2 == 0 ? (long)B * HW * 4 : (long)B * HW * 8));
     const int nblk = (int)((lanes + kThreads - 1) / kThreads < kFusedBlocks ? (lanes + kThreads - 1) / kThreads : kFusedBlocks);
     if (C == 36)
-      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 4, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
-                         ws, B, HW);
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 4, 4>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, (const float*)nullptr,
+                         (const float*)nullptr, mean, rstd, addend, gx, ws, B, HW);
     else if (C == 72)                                         // eight lanes x 9 channels per pixel pair: 44.8 -> 39 us at 100x150 (four x 18: more registers, fewer waves)
-      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 2, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
-                         ws, B, HW);
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 2, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, (const float*)nullptr,
+                         (const float*)nullptr, mean, rstd, addend, gx, ws, B, HW);
     else if (HW % 2 == 0)                                     // two pixels per lane group: 38.5 -> 30.4 us at 8x144x50x75
-      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
-                         ws, B, HW);
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, (const float*)nullptr,
+                         (const float*)nullptr, mean, rstd, addend, gx, ws, B, HW);
     else
-      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 1, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, mean, rstd, addend, gx,
-                         ws, B, HW);
+      hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 1, 8>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, (const float*)nullptr,
+                         (const float*)nullptr, mean, rstd, addend, gx, ws, B, HW);
     CIDNET_LAUNCH_STATUS();
-    hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb, accumulate);
+    hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb, accumulate, 2 * C, 0);
     CIDNET_LAUNCH_STATUS();
     return CIDNET_OK;
   }
@@ -499,6 +528,62 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
 int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd, float* gx,
                      float* gw, float* gb, float* ws, long ws_floats, int B, int C, long HW, void* stream) {
   return cidnet_ln_cf_bwd_res(x, weight, gy, mean, rstd, nullptr, gx, gw, gb, 0, ws, ws_floats, B, C, HW, stream);
+}
+
+/* ---- two LayerNorm modules on one tensor (see cidnet_hip.h) ---- */
+static bool ln_dual_shape(int B, int C, long HW) {
+  return (C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0) || (C == 144 && (long)B * HW <= (1L << 18));
+}
+
+int cidnet_ln_cf_dual_supported(int B, int C, long HW) { return B > 0 && HW > 0 && ln_dual_shape(B, C, HW) ? 1 : 0; }
+
+long cidnet_ln_cf_bwd2_ws_floats(int C) { return 4L * C * kFusedBlocks; }
+
+int cidnet_ln_cf_fwd2(const float* x, const float* weight, const float* bias, float* y, const float* weight2, const float* bias2,
+                      float* y2, float* mean, float* rstd, int B, int C, long HW, float eps, void* stream) {
+  CIDNET_CHECK_ARG(x && weight && bias && y && weight2 && bias2 && y2 && mean && rstd && B > 0 && C > 0 && HW > 0);
+  if (!ln_dual_shape(B, C, HW)) return CIDNET_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 36)
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y, weight2,
+                       bias2, y2, mean, rstd, B, HW, eps);
+  else if (C == 72)
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<72, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y, weight2,
+                       bias2, y2, mean, rstd, B, HW, eps);
+  else
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<144, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y, weight2,
+                       bias2, y2, mean, rstd, B, HW, eps);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_ln_cf_bwd2(const float* x, const float* weight, const float* gy, const float* weight2, const float* gy2,
+                      const float* mean, const float* rstd, const float* addend, float* gx, float* gw, float* gb, int accumulate,
+                      float* gw2, float* gb2, int accumulate2, float* ws, long ws_floats, int B, int C, long HW, void* stream) {
+  CIDNET_CHECK_ARG(x && weight && gy && weight2 && gy2 && mean && rstd && gx && gw && gb && gw2 && gb2 && ws && B > 0 && C > 0 && HW > 0);
+  if (!ln_dual_shape(B, C, HW)) return CIDNET_ERR_SHAPE;
+  if (ws_floats < cidnet_ln_cf_bwd2_ws_floats(C)) return CIDNET_ERR_WS;
+  hipStream_t s = (hipStream_t)stream;
+  const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 4 : (HW % 2 == 0 ? (long)B * HW * 4 : (long)B * HW * 8));
+  const int nblk = (int)((lanes + kThreads - 1) / kThreads < kFusedBlocks ? (lanes + kThreads - 1) / kThreads : kFusedBlocks);
+  if (C == 36)            // two pixels per lane: 179 VGPRs; four (as in the single-module kernel) need 295 and run no faster than two passes
+    hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 2, 4, true>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, weight2, gy2, mean,
+                       rstd, addend, gx, ws, B, HW);
+  else if (C == 72)
+    hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<9, 2, 8, true>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, weight2, gy2, mean,
+                       rstd, addend, gx, ws, B, HW);
+  else if (HW % 2 == 0)
+    hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 2, 8, true>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, weight2, gy2, mean,
+                       rstd, addend, gx, ws, B, HW);
+  else
+    hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<18, 1, 8, true>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gy, weight2, gy2, mean,
+                       rstd, addend, gx, ws, B, HW);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb, accumulate, 4 * C, 0);
+  CIDNET_LAUNCH_STATUS();
+  hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw2, gb2, accumulate2, 4 * C, 2 * C);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
 }
 
 }  // extern "C"

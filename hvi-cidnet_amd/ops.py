@@ -466,6 +466,69 @@ class LayerNormResFn(torch.autograd.Function):
         return gx, (gw if hand else None), (gb if hand else None), None, None
 
 
+LN_DUAL = {"on": os.environ.get("CIDNET_LN_DUAL", "1") == "1"}
+
+
+def ln_dual_supported(x):
+    B, C, H, W = x.shape
+    return LN_DUAL["on"] and x.is_cuda and x.dtype == torch.float32 and bool(_raw("cidnet_ln_cf_dual_supported", B, C, H * W))
+
+
+class LayerNormDualFn(torch.autograd.Function):
+    """Two LayerNorm modules on one tensor: (norm_a(x), norm_b(x), x).  In an LCA pair (net/CIDNet.py:83-84) every input is
+    the x of its own block (norm_a, and the block's residual: third output, as in LayerNormResFn) and the y of the partner
+    block (norm_b): one forward pass reads x once and writes both outputs, one backward pass reads x once and adds the
+    three gradients.  Module a's parameter gradients follow the in-place protocol of LNUse (`state_a`); module b lives on the
+    OTHER branch's stream, so its gradients are returned to autograd as fresh tensors (its own uses keep their protocol)."""
+
+    @staticmethod
+    def forward(ctx, x, w_a, b_a, w_b, b_b, eps, state_a=None):
+        _check(x, w_a, b_a)
+        _check(x, w_b, b_b)
+        x = _c(x)
+        B, C, H, W = x.shape
+        ya, yb = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        lib().call("cidnet_ln_cf_fwd2", _p(x), _p(w_a), _p(b_a), _p(ya), _p(w_b), _p(b_b), _p(yb), _p(mean), _p(rstd), B, C, H * W,
+                   _f(eps), _stream())
+        ctx.save_for_backward(x, w_a, b_a, w_b, b_b, mean, rstd)
+        _ln_forward_count(ctx, state_a)
+        return ya, yb, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gya, gyb, gres):
+        x, w_a, b_a, w_b, b_b, mean, rstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gw, gb, acc, hand = _ln_param_grads(ctx, w_a, b_a)
+        gres = _c(gres) if gres is not None else None
+        n1 = _raw("cidnet_ln_cf_bwd_ws_floats", C)
+        if gya is not None and gyb is not None:
+            gya, gyb = _c(gya), _c(gyb)
+            gx = torch.empty_like(x)
+            gw2, gb2 = torch.empty_like(w_b), torch.empty_like(b_b)
+            ws = _ws(max(n1, _raw("cidnet_ln_cf_bwd2_ws_floats", C)), x.device)
+            lib().call("cidnet_ln_cf_bwd2", _p(x), _p(w_a), _p(gya), _p(w_b), _p(gyb), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw),
+                       _p(gb), int(acc), _p(gw2), _p(gb2), 0, _p(ws), ws.numel(), B, C, H * W, _stream())
+            return gx, (gw if hand else None), (gb if hand else None), gw2, gb2, None, None
+        # one of the two outputs was not used: the single-module kernel (or nothing) does the work
+        ws = _ws(n1, x.device)
+        gx, gw2, gb2 = gres, None, None
+        if gya is not None:
+            gx = torch.empty_like(x)
+            lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(w_a), _p(_c(gya)), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw), _p(gb),
+                       int(acc), _p(ws), ws.numel(), B, C, H * W, _stream())
+        elif not acc:
+            gw.zero_(); gb.zero_()
+        if gyb is not None:
+            gx2 = torch.empty_like(x)
+            gw2, gb2 = torch.empty_like(w_b), torch.empty_like(b_b)
+            lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(w_b), _p(_c(gyb)), _p(mean), _p(rstd), _p(gx), _p(gx2), _p(gw2), _p(gb2), 0,
+                       _p(ws), ws.numel(), B, C, H * W, _stream())
+            gx = gx2
+        return gx, (gw if hand else None), (gb if hand else None), gw2, gb2, None, None
+
+
 # --------------------------------------------------------------------------------------------
 # K6/K7: cross-attention block with the residual:  out = x_res + CAB(xn, yn)
 # --------------------------------------------------------------------------------------------

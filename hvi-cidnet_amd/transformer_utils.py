@@ -35,6 +35,16 @@ class LayerNorm(nn.Module):
         return ops.LayerNormResFn.apply(x, self.weight, self.bias, self.eps,
                                         self._use if ops.needs_grad(x, self.weight, self.bias) else None)
 
+    def forward_dual(self, x, other):
+        """(self(x), other(x), x): this module's norm (x-norm of its block; the third value is the block's residual input, as
+        in forward_res) and the partner block's y-norm of the same tensor in one pass (ops.LayerNormDualFn).  Falls back
+        to two passes when the shape has no dual kernel or the eps differ."""
+        if not (ops.ln_dual_supported(x) and self.eps == other.eps and other.data_format == "channels_first"):
+            n, xr = self.forward_res(x)
+            return n, other(x), xr
+        grad = ops.needs_grad(x, self.weight, self.bias, other.weight, other.bias)
+        return ops.LayerNormDualFn.apply(x, self.weight, self.bias, other.weight, other.bias, self.eps, self._use if grad else None)
+
 
 class NormDownsample(nn.Module):
     """Reference: net/transformer_utils.py:31-48.  `down` keeps the reference's Sequential(Conv2d,

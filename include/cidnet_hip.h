@@ -78,6 +78,21 @@ int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, c
                          const float* addend, float* gx, float* gw, float* gb, int accumulate, float* ws,
                          long ws_floats, int B, int C, long HW, void* stream);
 
+/* Two LayerNorm MODULES applied to one tensor (the x-norm of an LCA block and the y-norm of its partner block read the same
+ * input, net/LCA.py:79-80,91-92 with net/CIDNet.py:83-84): one pass reads x and writes both outputs; one backward pass reads
+ * x once and returns gx = LN'(gy*w + gy2*w2) (+ addend) and both modules' parameter gradients (each with its own
+ * accumulate flag).  _supported: the shapes of the register-resident kernels (C = 36 with HW % 4 == 0, C = 72 with HW % 2 == 0,
+ * C = 144 on planes of at most 2^18 pixels per batch); otherwise CIDNET_ERR_SHAPE -- call the single-module entry points. */
+int cidnet_ln_cf_dual_supported(int B, int C, long HW);
+long cidnet_ln_cf_bwd2_ws_floats(int C);
+int cidnet_ln_cf_fwd2(const float* x, const float* weight, const float* bias, float* y, const float* weight2,
+                      const float* bias2, float* y2, float* mean, float* rstd, int B, int C, long HW, float eps,
+                      void* stream);
+int cidnet_ln_cf_bwd2(const float* x, const float* weight, const float* gy, const float* weight2, const float* gy2,
+                      const float* mean, const float* rstd, const float* addend, float* gx, float* gw, float* gb,
+                      int accumulate, float* gw2, float* gb2, int accumulate2, float* ws, long ws_floats, int B, int C,
+                      long HW, void* stream);
+
 /* ---- K4: pointwise (1x1) convolution on the fp32 MFMA -----------------------------------------
  * (nn.Conv2d(k=1): net/LCA.py:13,15,17,51,57; net/transformer_utils.py:60)
  * Per sample b:  Y[b] (M x HW) = A_b (M x K) * X[b] (K x HW)  [+ R[b]],

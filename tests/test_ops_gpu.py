@@ -79,6 +79,47 @@ def test_layernorm(dev, B, C, H, W):
     close(bd.grad, br.grad, what="gb")
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 36, 8, 12), (1, 72, 5, 6), (2, 144, 5, 7), (1, 144, 6, 6), (3, 36, 10, 10), (1, 36, 7, 9)])
+@pytest.mark.parametrize("use", ["both", "a", "b", "res"])
+def test_layernorm_dual(dev, B, C, H, W, use):
+    """ops.LayerNormDualFn: two LayerNorm modules on one tensor in one forward and one backward pass (the x-norm of an LCA
+    block and the y-norm of its partner).  Outputs bit-equal to the single-module kernel; all gradients (input incl. the
+    residual hand-over, both modules' weight and bias) against the oracle's autograd, also when one output is unused; the last
+    shape has no dual kernel (H*W odd for C = 36) and takes the two-pass route through LayerNorm.forward_dual."""
+    from hvi_cidnet_amd import ops
+    import hvi_cidnet_amd as P
+    x = rnd(51, (B, C, H, W), 2.0)
+    wa, ba, wb, bb = 1 + rnd(52, (C,), 0.2), rnd(53, (C,), 0.1), 1 + rnd(54, (C,), 0.3), rnd(55, (C,), 0.2)
+    ga, gb_, gr = rnd(56, (B, C, H, W)), rnd(57, (B, C, H, W)), rnd(58, (B, C, H, W))
+    xr, war, bar, wbr, bbr = (t.clone().requires_grad_(True) for t in (x, wa, ba, wb, bb))
+    ya_r, yb_r = O.layernorm_cf(xr, war, bar), O.layernorm_cf(xr, wbr, bbr)
+    na, nb = P.LayerNorm(C).to(dev), P.LayerNorm(C).to(dev)
+    with torch.no_grad():
+        na.weight.copy_(wa); na.bias.copy_(ba); nb.weight.copy_(wb); nb.bias.copy_(bb)
+    xd = x.to(dev).requires_grad_(True)
+    assert bool(ops.ln_dual_supported(xd)) == (not (C == 36 and (H * W) % 4) and not (C == 72 and (H * W) % 2))
+    ya, yb, xres = na.forward_dual(xd, nb)
+    assert torch.equal(ya, ops.LayerNormCFFn.apply(xd.detach(), na.weight.detach(), na.bias.detach(), 1e-6))
+    assert torch.equal(yb, ops.LayerNormCFFn.apply(xd.detach(), nb.weight.detach(), nb.bias.detach(), 1e-6))
+    assert xres.data_ptr() == xd.data_ptr()
+    outs, refs, grads = [], [], []
+    if use in ("both", "a"):
+        outs.append(ya); refs.append(ya_r); grads.append(ga)
+    if use in ("both", "b"):
+        outs.append(yb); refs.append(yb_r); grads.append(gb_)
+    if use in ("both", "res"):
+        outs.append(xres); refs.append(xr * 1.0); grads.append(gr)
+    torch.autograd.backward(refs, grads)
+    torch.autograd.backward(outs, [g.to(dev) for g in grads])
+    close(xd.grad, xr.grad, what="gx")
+    for mod, wr_, br_, used in ((na, war, bar, use in ("both", "a")), (nb, wbr, bbr, use in ("both", "b"))):
+        if used:
+            close(mod.weight.grad, wr_.grad, what="gw")
+            close(mod.bias.grad, br_.grad, what="gb")
+        else:
+            assert mod.weight.grad is None or float(mod.weight.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 12, 9, 13), (1, 190, 20, 30), (1, 6, 50, 75), (2, 3, 17, 66)])
 def test_dw3x3(dev, B, C, H, W):
     from hvi_cidnet_amd import ops

@@ -6,6 +6,11 @@ import torch
 from hvi_cidnet_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+if os.environ.get("WG_DBG_FLAGS"):            # -DCIDNET_DEBUG library only (32 = the previous block order)
+    import ctypes
+    from hvi_cidnet_amd._lib import lib
+    f = lib().raw("cidnet_debug_pw_flags"); f.argtypes = [ctypes.c_int]; f.restype = None
+    f(int(os.environ["WG_DBG_FLAGS"]))
 
 
 def run(dy, x, dw, B, M, N, HW, bf3, iters=20):
