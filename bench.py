@@ -122,6 +122,12 @@ def conv3x_flops(args):
     return 2.0 * 9 * M * K * H * W * B
 
 
+def conv3x_bytes(args):
+    # X (K channels) once + Y (M channels) once (+ the addend R): the compulsory HBM bytes of one launch
+    R, B, M, K, H, W = args[6], args[12], args[13], args[14], args[15], args[16]
+    return (K + M + (M if R is not None else 0)) * 4.0 * H * W * B
+
+
 def pw_work(name, args):
     """(algorithmic FLOPs, algorithmic HBM bytes: every operand once) of one launch of the 1x1-conv family, from the call's
     own arguments (include/cidnet_hip.h); None for other entry points"""
@@ -372,6 +378,7 @@ def main():
                     "frac": round(6 * eq / PEAK_BF16_MFMA_TFLOPS, 4),
                     "fp32_equivalent_tflops": round(eq, 2), "vs_fp32_mfma_peak": round(eq / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": pmc_traffic("conv3x"), "traffic_source": PMC_TRAFFIC_FILE,
+                    "alg_bytes_per_launch": int(sum(conv3x_bytes(ar) for ar, _ in cx) / max(len(cx), 1)),
                     "launches_per_step": len(cx) // 2, "avg_launch_ms": round(cx_ms / max(len(cx), 1), 4),
                     "measured_in": "2 extra single-stream steps after the timed region (HIP events per launch)",
                     "share_of_step_kernel_time": round(cx_ms / tot, 3) if tot else None,

@@ -10,6 +10,12 @@ from .hvi_transform import RGB_HVI
 from .lca import HV_LCA, I_LCA
 from .transformer_utils import NormDownsample, NormUpsample
 
+# With `dual_norms` a LayerNorm module's weight / bias receive one gradient contribution from the OTHER branch's stream (the
+# partner block's y-norm is computed next to this tensor's x-norm): intentional, and autograd synchronises the streams for it
+# -- only its "AccumulateGrad node's stream does not match" warning is switched off.
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 try:  # the reference mixes this in for from_pretrained/save_pretrained (net/CIDNet.py:6,8)
     from huggingface_hub import PyTorchModelHubMixin as _HubMixin
 except Exception:  # pragma: no cover - hub client not installed
