@@ -357,6 +357,25 @@ def prelu_bwd(go, pre, slope):
 # --------------------------------------------------------------------------------------------
 # K3: LayerNorm (channels first)
 # --------------------------------------------------------------------------------------------
+# Backward of a 1x1 conv as ONE kernel (csrc/pwb.hip): data gradient and weight gradient from one read of gy.
+# CIDNET_PW_BWD_FUSED=0 keeps the two separate launches (data gradient on the main stream, weight gradient on its own).
+PW_BWD_FUSED = {"on": os.environ.get("CIDNET_PW_BWD_FUSED", "1") == "1"}
+
+
+def pw_bwd_fused_ok(gy, x, w, M, N, HW):
+    return (PW_BWD_FUSED["on"] and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32
+            and gy.is_contiguous() and x.is_contiguous() and w.is_contiguous()
+            and bool(_raw("cidnet_pw_bwd_fused_supported", M, N, HW)))
+
+
+def pw_bwd_fused(gy, x, w, gx, dw, B, M, N, HW):
+    """gx (B, N, HW) = W^T gy and dw (M, N) = sum gy x^T for y = W x with W (M, N); fp32, contiguous"""
+    n = _raw("cidnet_pw_bwd_fused_ws_floats", B, M, N, HW)
+    ws = _ws(n, gy.device)
+    lib().call("cidnet_pw_bwd_fused", _p(gy), M * HW, _p(x), N * HW, _p(w), _p(gx), N * HW, _p(dw), _p(ws), ws.numel(), B, M, N, HW,
+               _stream())
+
+
 class LNUse:
     """Per-module bookkeeping for a LayerNorm that is applied several times per step (net/LCA.py:79-80,91-92: one `norm`
     per LCA, used on x, on y and on the CAB output).  With `acc` set (by dp.DataParallelTrainer, after its probing step has
@@ -663,9 +682,12 @@ class IELFn(torch.autograd.Function):
         h = w_dw1.shape[0]
         go = _c(go)
         g_wout = grad_like(w_out)
-        _offload_wgrad((go, gate, g_wout), lambda: pw_wgrad(go, 0, C * HW, gate, 0, h * HW, g_wout, 0, h, B, C, h, HW))
         dg = torch.empty_like(gate)                     # hidden tensors keep the storage type they were saved in
-        pw_conv(go, 0, C * HW, w_out, 0, 0, 1, h, dg, 0, h * HW, B, h, C, HW)
+        if pw_bwd_fused_ok(go, gate, w_out, C, h, HW):
+            pw_bwd_fused(go, gate, w_out, dg, g_wout, B, C, h, HW)
+        else:
+            _offload_wgrad((go, gate, g_wout), lambda: pw_wgrad(go, 0, C * HW, gate, 0, h * HW, g_wout, 0, h, B, C, h, HW))
+            pw_conv(go, 0, C * HW, w_out, 0, 0, 1, h, dg, 0, h * HW, B, h, C, HW)
         g_dw1 = grad_like(w_dw1)
         g_dw2 = grad_like(w_dw2)
         du = torch.empty_like(u)                        # gate backward + dwconv1/2 backward in one pass
@@ -677,11 +699,15 @@ class IELFn(torch.autograd.Function):
         dpin = torch.empty_like(u)
         dw3x3_bwd(pin, du, w_dw, None, 2 * h, dpin, g_dw, None, B, 2 * h, H, W)
         g_win = grad_like(w_in)
-        _offload_wgrad((dpin, xn, g_win), lambda: pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW))
         dxn = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and pw_bwd_fused_ok(dpin, xn, w_in, 2 * h, C, HW):
             dxn = torch.empty_like(xn)
-            pw_conv(dpin, 0, 2 * h * HW, w_in, 0, 0, 1, C, dxn, 0, C * HW, B, C, 2 * h, HW)
+            pw_bwd_fused(dpin, xn, w_in, dxn, g_win, B, 2 * h, C, HW)
+        else:
+            _offload_wgrad((dpin, xn, g_win), lambda: pw_wgrad(dpin, 0, 2 * h * HW, xn, 0, C * HW, g_win, 0, C, B, 2 * h, C, HW))
+            if ctx.needs_input_grad[0]:
+                dxn = torch.empty_like(xn)
+                pw_conv(dpin, 0, 2 * h * HW, w_in, 0, 0, 1, C, dxn, 0, C * HW, B, C, 2 * h, HW)
         return dxn, (go if ctx.has_res else None), g_win, g_dw, g_dw1, g_dw2, g_wout, None
 
 

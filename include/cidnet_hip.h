@@ -121,6 +121,15 @@ int cidnet_pw_conv_bf16x3_supported(int M, int K, long HW);
 long cidnet_pw_conv_bf16x3_ws_floats(int B, int M, int K, int per_sample);
 int cidnet_pw_conv_bf16x3(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
                           const float* R, long r_bs, float* ws, long ws_floats, int B, int M, int K, long HW, void* stream);
+/* Backward of a 1x1 convolution Y = W X (W: (M, N) contiguous) in one kernel: gX (B, N, HW) = W^T gY and dW (M, N) = sum over
+ * samples and pixels of gY X^T (overwritten; partial sums combined in fixed order).  gY is read from HBM once instead of once
+ * by the data-gradient launch (cidnet_pw_conv* with transposed strides) and once by cidnet_pw_wgrad*.  fp32 tensors, split
+ * bf16 products as cidnet_pw_conv_bf16x3.  _supported: the IEL / CAB layer shapes of the 36-channel level (M x N tiles
+ * 12x3, 3x6, 3x3, 5x3) with HW a multiple of 4; other shapes CIDNET_ERR_SHAPE -- use the two separate entry points. */
+int cidnet_pw_bwd_fused_supported(int M, int N, long HW);
+long cidnet_pw_bwd_fused_ws_floats(int B, int M, int N, long HW);
+int cidnet_pw_bwd_fused(const float* gY, long gy_bs, const float* X, long x_bs, const float* Wt, float* gX, long gx_bs,
+                        float* dW, float* ws, long ws_floats, int B, int M, int N, long HW, void* stream);
 /* NormUpsample tail (net/transformer_utils.py:64-66): pre = Wt*X + bilinear_x2(Z), Y = PReLU(pre).
  * Z: (B,M,zh,zw) low-resolution, X: skip tensor (B,K,2zh,2zw), Y/Ypre: (B,M,2zh,2zw); Ypre may be NULL (inference). */
 int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks,

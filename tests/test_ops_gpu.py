@@ -120,6 +120,35 @@ def test_layernorm_dual(dev, B, C, H, W, use):
             assert mod.weight.grad is None or float(mod.weight.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,M,N,HW", [(2, 190, 36, 600), (1, 36, 95, 1000), (3, 36, 36, 96), (2, 72, 36, 404), (1, 190, 36, 32),
+                                      (5, 181, 33, 260), (1, 36, 95, 12)])
+def test_pw_bwd_fused(dev, B, M, N, HW):
+    """csrc/pwb.hip: data gradient and weight gradient of a 1x1 conv in one kernel, against fp64 and no less accurate than
+    the two separate kernels; ragged last chunk (HW not a multiple of 32), channel counts inside a tile, planes smaller
+    than a chunk; NaN-prefilled outputs, reruns bit-identical"""
+    from hvi_cidnet_amd import ops
+    assert ops._raw("cidnet_pw_bwd_fused_supported", M, N, HW)
+    gy, x, w = rnd(61, (B, M, HW)), rnd(62, (B, N, HW)), rnd(63, (M, N), 0.3)
+    gx_ref = torch.einsum("mn,bmp->bnp", w.double(), gy.double())
+    dw_ref = torch.einsum("bmp,bnp->mn", gy.double(), x.double())
+    gyd, xd, wd = gy.to(dev), x.to(dev), w.to(dev)
+    outs = []
+    for _ in range(2):
+        gx = torch.full((B, N, HW), float("nan"), device=dev)
+        dw = torch.full((M, N), float("nan"), device=dev)
+        ops.pw_bwd_fused(gyd, xd, wd, gx, dw, B, M, N, HW)
+        outs.append((gx, dw))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    close(outs[0][0], gx_ref.float(), what="gx")
+    close(outs[0][1], dw_ref.float(), what="dw")
+    gx2, dw2 = torch.empty_like(outs[0][0]), torch.empty_like(outs[0][1])
+    ops.pw_conv(gyd, 0, M * HW, wd, 0, 0, 1, N, gx2, 0, N * HW, B, N, M, HW)        # data gradient: transposed strides
+    ops.pw_wgrad(gyd, 0, M * HW, xd, 0, N * HW, dw2, 0, N, B, M, N, HW)
+    for a, b, ref in ((outs[0][0], gx2, gx_ref), (outs[0][1], dw2, dw_ref)):
+        ea, eb = (a.double().cpu() - ref).abs().max().item(), (b.double().cpu() - ref).abs().max().item()
+        assert ea <= 2.0 * eb + 1e-6 * ref.abs().max().item(), (ea, eb)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 12, 9, 13), (1, 190, 20, 30), (1, 6, 50, 75), (2, 3, 17, 66)])
 def test_dw3x3(dev, B, C, H, W):
     from hvi_cidnet_amd import ops
