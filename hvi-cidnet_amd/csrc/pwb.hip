@@ -187,6 +187,10 @@ __global__ __launch_bounds__(kBThreads, 2) void pwb_kernel(PwbArgs a) {
       *reinterpret_cast<uint2*>(dst + 2 * lvl) = uint2{a2, b2};
     }
     __syncthreads();
+    // (Measured alternatives, both slower at 190 x 36, 200x300: reloading a round's registers right after its split inside the
+    // loop above -- the compiler cannot order the previous iteration's loads against this iteration's and waits vmcnt(0)
+    // before every round: 168 -> 265 us; the data gradient computed transposed for 16-byte stores along pixels -- 64 lanes
+    // then write 64 different channel rows per instruction: 168 -> 191 us.)
     if (c + (int)gridDim.x < a.nchunks_all) load_chunk(c + gridDim.x);
 
     // ---- data gradient: this wave's n-tiles x the chunk's two 16-pixel tiles, k = all rows of gy ----
