@@ -142,6 +142,9 @@ def pw_work(name, args):
         Ypre, B, M, K, zh, zw = args[8], args[9], args[10], args[11], args[12], args[13]
         hw = 4 * zh * zw
         return 2.0 * M * K * hw * B, ((K + M + (M if Ypre is not None else 0)) * hw + M * zh * zw) * 4 * B
+    if name == "cidnet_pw_bwd_fused":     # (gY, gy_bs, X, x_bs, Wt, gX, gx_bs, dW, ws, ws_floats, B, M, N, HW, stream): both products
+        B, M, N, HW = args[10], args[11], args[12], args[13]
+        return 4.0 * M * N * HW * B, (M + 2 * N) * 4 * HW * B
     if name == "cidnet_pw_wgrad_t":       # (dY, dy_dt, dy_bs, X, x_dt, x_bs, dW, dw_ld, per_sample, acc, ws, ws_floats, B, M, N, HW, stream)
         dy_dt, x_dt, B, M, N, HW = args[1], args[4], args[12], args[13], args[14], args[15]
         return 2.0 * M * N * HW * B, (M * es(dy_dt) + N * es(x_dt)) * HW * B
@@ -396,7 +399,7 @@ def main():
         # the family that bounds the step: the 1x1 convs and their weight gradients
         pw = [(pw_work(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if pw_work(name, args) is not None]
         pw_fl, pw_by, pw_ms = sum(w[0] for w, _ in pw), sum(w[1] for w, _ in pw), sum(t for _, t in pw)
-        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3, cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t)",
+        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3, cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t, cidnet_pw_bwd_fused)",
                    "achieved": round(pw_by / (pw_ms * 1e-3) / 1e9, 1) if pw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": round(pw_by / (pw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if pw_ms > 0 else 0.0,
                    "tflops": round(pw_fl / (pw_ms * 1e-3) / 1e12, 2) if pw_ms > 0 else 0.0,

@@ -10,7 +10,7 @@ import collections, csv, json, sys
 fetch_csv, write_csv, out = sys.argv[1:4]
 FAMILIES = collections.OrderedDict([
     ("conv3x", ("conv3x_kernel",)), ("conv3xw", ("conv3xw_",)), ("conv3", ("conv3_kernel",)), ("conv3_wgrad", ("conv3_wgrad",)),
-    ("pw", ("pw_conv", "pwx_kernel", "pw_wgrad", "pw_splitk", "pw_up")), ("dw_iel", ("dw3x3", "iel_")), ("ln", ("ln_",)),
+    ("pw", ("pw_conv", "pwx_kernel", "pw_wgrad", "pw_splitk", "pw_up", "pwb_kernel")), ("dw_iel", ("dw3x3", "iel_")), ("ln", ("ln_",)),
 ])
 
 
