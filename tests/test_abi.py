@@ -107,3 +107,46 @@ def test_inline_asm_loads_are_not_read_before_their_wait(tmp_path):
         lines.insert(bar + 1, f"\tv_mov_b32_e32 v250, v{reg}")
         assert asm_load_hazard.check("\n".join(lines), "conv3xw_kernel")[1]
     assert found
+
+
+def test_asm_load_hazard_checker_on_synthetic_assembly():
+    """tools/asm_load_hazard.py models vmcnt as an in-order queue over the kernel's basic blocks: a read of a pending
+    destination is found across a loop edge, a counted wait retires only the older loads, and clean code passes"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import asm_load_hazard as h
+    finally:
+        sys.path.pop(0)
+    clean = """
+k_kernel:
+\tglobal_load_dwordx4 v[0:3], v[10:11], off
+.LBB0_1:
+\ts_waitcnt vmcnt(0)
+\tv_add_f32_e32 v20, v0, v1
+\tglobal_load_dwordx4 v[0:3], v[10:11], off
+\ts_barrier
+\ts_cbranch_scc1 .LBB0_1
+\ts_waitcnt vmcnt(0)
+\ts_endpgm
+"""
+    assert h.check(clean, "k_kernel") == (2, [])
+    # a copy of the destination right after the barrier, i.e. before the wait at the loop top
+    loop_edge = clean.replace("\ts_barrier\n", "\ts_barrier\n\tv_mov_b32_e32 v30, v2\n")
+    assert h.check(loop_edge, "k_kernel")[1] == ["v_mov_b32_e32 v30, v2"]
+    # vmcnt(1) retires the older of two loads only
+    counted = """
+k_kernel:
+\tglobal_load_dwordx4 v[0:3], v[10:11], off
+\tglobal_load_dwordx4 v[4:7], v[12:13], off
+\ts_waitcnt vmcnt(1)
+\tv_add_f32_e32 v20, v0, v1
+\tv_add_f32_e32 v21, v4, v5
+\ts_waitcnt vmcnt(0)
+\ts_endpgm
+"""
+    assert h.check(counted, "k_kernel")[1] == ["v_add_f32_e32 v21, v4, v5"]
+    # an address register that is itself a pending destination
+    addr = counted.replace("\ts_waitcnt vmcnt(1)\n", "\tglobal_load_dwordx4 v[8:11], v[4:5], off\n\ts_waitcnt vmcnt(0)\n")
+    assert h.check(addr, "k_kernel")[1] == ["global_load_dwordx4 v[8:11], v[4:5], off"]
