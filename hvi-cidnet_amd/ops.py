@@ -237,17 +237,17 @@ def _pe(t, off_elems=0):
     return _vp(t.data_ptr() + t.element_size() * int(off_elems))
 
 
-# 1x1 convs that the fp32 MFMA rate bounds (many channels on small planes) or that reduce over many channels run on the BF16
-# matrix cores with exact three-way split operands (csrc/pwx.hip).  Taken where it measures faster than pw.hip
-# (tools/micro_pwx.py, profiles/r03_d_micro_pwx.txt: reduction-heavy shapes 1.2-1.7x; shapes that fan out to many output
-# channels from few inputs stay on pw.hip, they are store-bound either way).  CIDNET_PW_BF16X3=0 switches it off.
+# The 1x1 convs run on the BF16 matrix cores with exact three-way split operands (csrc/pwx.hip, third version: every wave
+# independent, operands split in registers).  It is faster than the fp32-MFMA kernel (pw.hip) on every 1x1 shape of the
+# step but one (tools/sweep_pw_step.py, profiles/r04_b_sweep_pw_step.txt: 1.03 - 2.0x; 3.9 - 4.6 TB/s on the 200x300 planes
+# where pw.hip reaches 2.2 - 4.0): the fan-out from 36 to 190 channels (IEL project_in at the 36-channel level, 0.94x), whose
+# two k-blocks of weights per 12 output tiles cost more than the fp32 kernel's register-resident panel.
+# CIDNET_PW_BF16X3=0 switches it off.
 PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "1") == "1"}
 
 
 def pw_bf16x3_wins(M, K, HW=0):
-    if HW and HW < 8000 and M * K <= 144 * 144:
-        return False
-    return K >= 95 or (K >= 72 and 72 <= M <= 150) or (M == 72 and K == 36)
+    return not (K <= 40 and M >= 150)
 
 
 def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):

@@ -114,9 +114,11 @@ int cidnet_pw_conv_t(const void* X, int x_dt, long x_bs, const float* Wt, long w
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
                    float* Y, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW,
                    void* stream);
-/* The same product on the BF16 matrix cores with exact three-way split operands (csrc/pws.hip; fp32 tensors only): for
- * launches bound by the fp32 MFMA rate (many channels on small planes).  ws: cidnet_pw_conv_bf16x3_ws_floats(B, M, K,
- * w_bs != 0) floats, 16-byte aligned (the weights, split once per call into MFMA fragment order). */
+/* The same product on the BF16 matrix cores with exact three-way split operands (csrc/pwx.hip; fp32 tensors only): for
+ * launches bound by the fp32 MFMA rate or by that kernel's instruction issue.  _supported: M > 16, HW >= 64 (any HW
+ * from there: the last 64-pixel group of a plane is pulled back to the plane's end), K * HW and M * HW below 2^31.
+ * ws: cidnet_pw_conv_bf16x3_ws_floats(B, M, K, w_bs != 0) floats, 16-byte aligned (the weights, split once per call into
+ * MFMA fragment order). */
 int cidnet_pw_conv_bf16x3_supported(int M, int K, long HW);
 long cidnet_pw_conv_bf16x3_ws_floats(int B, int M, int K, int per_sample);
 int cidnet_pw_conv_bf16x3(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,

@@ -470,14 +470,16 @@ def test_conv3x3_bf16x3_split_products(dev, B, M, K, H, W, flip, add):
 @pytest.mark.parametrize("B,M,K,HW,res,form", [
     (2, 144, 766, 3750, False, "fwd"), (2, 766, 144, 3750, True, "fwd"), (3, 72, 382, 1501, True, "fwd"),
     (2, 36, 36, 999, False, "fwd"), (1, 20, 32, 64, False, "fwd"), (2, 191, 72, 777, False, "dgrad"),
-    (2, 144, 144, 1000, True, "per_sample"), (1, 17, 7, 19, True, "fwd"), (2, 95, 36, 4, True, "fwd"), (1, 288, 288, 3750, False, "dgrad")])
+    (2, 144, 144, 1000, True, "per_sample"), (1, 17, 7, 67, True, "fwd"), (2, 95, 36, 64, True, "fwd"), (1, 288, 288, 3750, False, "dgrad"),
+    (2, 72, 72, 15000, True, "fwd"), (2, 60, 95, 130, True, "fwd"), (1, 383, 144, 3750, True, "fwd"), (2, 36, 95, 1502, True, "dgrad")])
 def test_pw_conv_bf16x3_split_products(dev, B, M, K, HW, res, form):
     """csrc/pwx.hip: the 1x1 conv on the BF16 matrix cores with exact three-way split operands against the fp64 product;
     bar = 3x the fp32-MFMA kernel's own error + 2e-6 of the output scale (the matrix core's fp32 accumulation of six
     products per term is a little looser than the fp32 MFMA at K = 766: 5e-6 against 1.3e-6).  Shapes: every block layout
-    (2, 4 waves along M; 1-3 channel tiles per wave; several channel chunks), ragged pixel / channel / K tails (planes whose
-    size is not a multiple of 4 or of 64, a 4-pixel plane), the data-gradient weight strides and per-sample weights
-    (attention fold); every output element written (NaN prefill) and a rerun bit-identical."""
+    (1, 2, 4 waves of a block on one pixel group; 2-5 channel tiles per wave; several channel chunks), ragged pixel /
+    channel / K tails (planes whose size is not a multiple of 4 or of 64 -- the last group is pulled back and stores only
+    the pixels it owns --, a 64-pixel plane), the data-gradient weight strides and per-sample weights (attention fold);
+    every output element written (NaN prefill) and a rerun bit-identical."""
     from hvi_cidnet_amd import ops
     g = torch.Generator(device=dev).manual_seed(M * 7 + K)
     x = torch.randn(B, K, HW, device=dev, generator=g)
