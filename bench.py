@@ -50,6 +50,7 @@ def parse():
                     help="with --full-loss: weight of the VGG19 perceptual term (train.py's P_weight, 1e-2 there; random VGG weights here)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the I and HV branches on one stream (default: two streams, kernels of the two branches overlap)")
+    ap.add_argument("--dual-norms", action="store_true", help="A/B: the two LayerNorms of an LCA input as one pass (CIDNet.dual_norms)")
     return ap.parse_args()
 
 
@@ -273,6 +274,7 @@ def main():
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream
+    model.dual_norms = a.dual_norms
     trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream),
                                   use_graph=a.graph, loss_fn=P.CIDNetLoss(model, P_weight=a.p_weight).to(dev) if a.full_loss else None)
     g = torch.Generator(device=dev)

@@ -10,11 +10,14 @@ from .hvi_transform import RGB_HVI
 from .lca import HV_LCA, I_LCA
 from .transformer_utils import NormDownsample, NormUpsample
 
-# With `dual_norms` a LayerNorm module's weight / bias receive one gradient contribution from the OTHER branch's stream (the
-# partner block's y-norm is computed next to this tensor's x-norm): intentional, and autograd synchronises the streams for it
-# -- only its "AccumulateGrad node's stream does not match" warning is switched off.
-if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
-    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+def _allow_cross_stream_param_grads():
+    """With `dual_norms` a LayerNorm module's weight / bias receive one gradient contribution from the OTHER branch's stream
+    (the partner block's y-norm is computed next to this tensor's x-norm): intentional, and autograd synchronises the
+    streams for it -- only its "AccumulateGrad node's stream does not match" warning is switched off, and only once a
+    model actually runs with dual_norms (not at import time)."""
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 
 try:  # the reference mixes this in for from_pretrained/save_pretrained (net/CIDNet.py:6,8)
     from huggingface_hub import PyTorchModelHubMixin as _HubMixin
@@ -98,11 +101,22 @@ class CIDNet(nn.Module, _HubMixin):
     def _gate(self, name, t):
         return t
 
-    def _i_dec2_input(self, i_dec3, hv_3):
-        # net/CIDNet.py:105 evaluates I_LCA5(i_dec3, hv_3) and :109 then ignores it (ID_block2 is fed
-        # i_dec3): the result never reaches the output and its 13 parameters get no gradient, so the
-        # dead block is not executed here.
-        return i_dec3
+    def _stage5(self, i_dec3, hv_3):
+        """-> (input of ID_block2, HV_LCA5(hv_3, i_dec3)).  net/CIDNet.py:105 evaluates I_LCA5(i_dec3, hv_3) and :109 then
+        ignores it (ID_block2 is fed i_dec3): the result never reaches the output and its 13 parameters get no gradient, so
+        the dead block is not executed here.  i_dec3 has two consumers, HV_LCA5's y-norm and ID_block2; it is threaded
+        through the norm (ops.LayerNormResFn hands it on as a view) so that ID_block2's gradient arrives in the LayerNorm
+        backward kernel instead of being summed by a separate autograd accumulation pass."""
+        blk = self.HV_LCA5
+        if not (self.chain_lca_inputs and torch.is_grad_enabled() and i_dec3.requires_grad):
+            return self._par(lambda: i_dec3, lambda: blk(hv_3, i_dec3), (i_dec3, hv_3))
+
+        def hv_side():
+            hv_n, hv_r = blk.norm.forward_res(hv_3)
+            i_n, i_pass = blk.norm.forward_res(i_dec3)
+            return blk.body(hv_n, i_n, hv_r), i_pass
+        _, (out_hv, i_pass) = self._par(lambda: None, hv_side, (i_dec3, hv_3))
+        return i_pass, out_hv
 
     # A down block whose input also feeds a skip connection (net/CIDNet.py:80-81,85-86): with `fold_skip_grads` the skip's
     # gradient is added in the epilogue of the block's data-gradient conv (ops.DownResFn) instead of by a separate autograd
@@ -167,7 +181,9 @@ class CIDNet(nn.Module, _HubMixin):
     # that), and the forward needs no extra synchronisation: t1 / t2 are views of t.
     chain_lca_inputs = True
     # the two norms that read the same LCA input as ONE pass (ops.LayerNormDualFn): x read once in the forward, once in the backward
-    dual_norms = True
+    # Off by default since round 4: alternating runs on one box showed no step gain (313.0 / 311.2 off, 313.4 / 312.8 on),
+    # and module b's gradients go through autograd (27 ATen adds and 20 copies per step on the other branch's stream).
+    dual_norms = False
 
     def _lca_pair(self, I_blk, HV_blk, i, hv):
         if not (self.chain_lca_inputs and torch.is_grad_enabled() and (i.requires_grad or hv.requires_grad)):
@@ -185,6 +201,7 @@ class CIDNet(nn.Module, _HubMixin):
             with torch.cuda.stream(side):
                 return f()
         if self.dual_norms and ops.ln_dual_supported(i) and ops.ln_dual_supported(hv):
+            _allow_cross_stream_param_grads()
             # one pass per input: its own block's x-norm (+ residual hand-over) and the partner block's y-norm of it
             hv_nhv, hv_ni, hv2 = on_side(lambda: HV_blk.norm.forward_dual(hv, I_blk.norm))
             i_ni, i_nhv, i2 = I_blk.norm.forward_dual(i, HV_blk.norm)
@@ -229,11 +246,15 @@ class CIDNet(nn.Module, _HubMixin):
             raise RuntimeError(f"CIDNet: H and W must be multiples of 8 (got {tuple(x.shape[2:])}); the reference "
                                "fails in NormUpsample's cat for other sizes (net/transformer_utils.py:64)")
         hvi = self.trans.HVIT(x)
-        i = hvi[:, 2:3, :, :].contiguous()
+        if torch.is_grad_enabled() and hvi.requires_grad:
+            # three consumers (HV stem, I stem on plane 2, output residual): one kernel sums their gradients
+            hvi_hv, i, hvi = ops.HviFanoutFn.apply(hvi)
+        else:
+            hvi_hv, i = hvi, hvi[:, 2:3, :, :]                     # the I stem reads the plane in place (no copy)
         # low
         (i_enc0, i_enc1), (hv_0, hv_1) = self._par(
             lambda: self._down_skip(self.IE_block1, self.IE_block0(i)),
-            lambda: self._down_skip(self.HVE_block1, self.HVE_block0(hvi)), (hvi, i))
+            lambda: self._down_skip(self.HVE_block1, self.HVE_block0(hvi_hv)), (hvi,))
         i_jump0 = i_enc0
         hv_jump0 = hv_0
 
@@ -241,9 +262,12 @@ class CIDNet(nn.Module, _HubMixin):
         (v_jump1, i_enc2), (hv_jump1, hv_2) = self._par(lambda: self._down_skip(self.IE_block2, i_enc2),
                                                         lambda: self._down_skip(self.HVE_block2, hv_2), (i_enc2, hv_2))
 
-        # reference quirk: level-3 encoders take the PRE-LCA2 tensors (net/CIDNet.py:94-95)
+        # reference quirk: level-3 encoders take the PRE-LCA2 tensors (net/CIDNet.py:94-95).  They run first here so that
+        # the LCA pair's gradient for those tensors enters the down blocks' data-gradient conv as an epilogue addend
+        # (ops.DownResFn) instead of a separate autograd accumulation pass; the values are the reference's either way.
+        (i_enc2, i_enc3), (hv_2, hv_3) = self._par(lambda: self._down_skip(self.IE_block3, i_enc2),
+                                                   lambda: self._down_skip(self.HVE_block3, hv_2), (i_enc2, hv_2))
         v_jump2, hv_jump2 = self._lca_pair(self.I_LCA2, self.HV_LCA2, i_enc2, hv_2)
-        i_enc3, hv_3 = self._par(lambda: self.IE_block3(i_enc2), lambda: self.HVE_block3(hv_2), (i_enc2, hv_2))
 
         i_enc4, hv_4 = self._lca_pair(self.I_LCA3, self.HV_LCA3, i_enc3, hv_3)
         i_dec4, hv_4b = self._lca_pair(self.I_LCA4, self.HV_LCA4, i_enc4, hv_4)
@@ -251,7 +275,7 @@ class CIDNet(nn.Module, _HubMixin):
         i_dec3, hv_3 = self._par(lambda: self._gate("sa_i3", self.ID_block3(i_dec4, v_jump2)),
                                  lambda: self._gate("sa_hv3", self.HVD_block3(hv_4b, hv_jump2)),
                                  (i_dec4, hv_4b, v_jump2, hv_jump2))
-        i_dec2, hv_2 = self._par(lambda: self._i_dec2_input(i_dec3, hv_3), lambda: self.HV_LCA5(hv_3, i_dec3), (i_dec3, hv_3))
+        i_dec2, hv_2 = self._stage5(i_dec3, hv_3)
 
         i_dec2, hv_2 = self._par(lambda: self._gate("sa_i2", self.ID_block2(i_dec2, v_jump1)),
                                  lambda: self._gate("sa_hv2", self.HVD_block2(hv_2, hv_jump1)),

@@ -37,5 +37,5 @@ class CIDNet(_BaseCIDNet):
     def _gate(self, name, t):                    # net/CIDNet_MSSA.py:133,135,142,144,150,153
         return getattr(self, name)(t)
 
-    def _i_dec2_input(self, i_dec3, hv_3):       # net/CIDNet_MSSA.py:137,143
-        return self.I_LCA5(i_dec3, hv_3)
+    def _stage5(self, i_dec3, hv_3):             # net/CIDNet_MSSA.py:137,143: ID_block2 is fed I_LCA5's output -- a live LCA pair
+        return self._lca_pair(self.I_LCA5, self.HV_LCA5, i_dec3, hv_3)

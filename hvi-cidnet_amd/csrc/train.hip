@@ -59,6 +59,30 @@ __global__ __launch_bounds__(kThreads) void scale_kernel(const float* __restrict
   }
 }
 
+// Gradient of the HVI image at its fan-out (net/CIDNet.py:73-77, 119: hvi feeds the HV stem, its third plane feeds the I stem
+// and the whole image is the residual of the output): out = ga + gc, plane 2 also + gi.  Any of the three may be null.
+__global__ __launch_bounds__(kThreads) void hvi_grad_sum_kernel(const float* __restrict__ ga, const float* __restrict__ gc,
+                                                                const float* __restrict__ gi, float* __restrict__ out, long HW,
+                                                                long quads_per_plane, long total_quads) {
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total_quads; q += (long)gridDim.x * blockDim.x) {
+    const long plane = q / quads_per_plane;                       // b * 3 + c
+    const long px = (q - plane * quads_per_plane) * 4;
+    const long o = plane * HW + px;
+    const int nv = (int)min(4L, HW - px);
+    const bool i_plane = gi && plane % 3 == 2;
+    const long oi = (plane / 3) * HW + px;
+    if (nv == 4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ga) v = load4u(ga + o);
+      if (gc) { const f32x4 t = load4u(gc + o); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+      if (i_plane) { const f32x4 t = load4u(gi + oi); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+      store4u(out + o, v);
+    } else {
+      for (int e = 0; e < nv; ++e) out[o + e] = (ga ? ga[o + e] : 0.f) + (gc ? gc[o + e] : 0.f) + (i_plane ? gi[oi + e] : 0.f);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                         float wd, float bc1, float bc2_sqrt, float gscale) {
@@ -102,6 +126,16 @@ int cidnet_scale(const float* x, const float* s, float mult, float* y, long n, v
   long g = ((n + 3) / 4 + kThreads - 1) / kThreads;
   const int grid = (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
   hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, x, s, mult, y, n);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_hvi_grad_sum(const float* ga, const float* gc, const float* gi, float* out, int B, long HW, void* stream) {
+  CIDNET_CHECK_ARG(out && B > 0 && HW > 0);
+  const long qpp = (HW + 3) / 4, total = qpp * 3 * B;
+  long g = (total + kThreads - 1) / kThreads;
+  const int grid = (int)(g > 8192 ? 8192 : g);
+  hipLaunchKernelGGL(hvi_grad_sum_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, ga, gc, gi, out, HW, qpp, total);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -333,10 +333,18 @@ class DataParallelTrainer:
             self.opt.lr = float(lr)
 
     # ---- hipGraph replay of forward + loss + backward ---------------------------------------------
+    def _backward(self, loss):
+        """loss.backward() with a cached unit gradient: autograd would otherwise launch an ATen fill for its implicit
+        ones_like(loss) every step (the step launches only cidnet:: kernels, tests/test_trainer_gpu.py)"""
+        one = getattr(self, "_unit_grad", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+            one = self._unit_grad = torch.ones_like(loss)
+        loss.backward(gradient=one)
+
     def _fwd_bwd(self, x, gt):
         self._begin_pass(x)
         loss = self.loss_fn(self.model(x), gt)
-        loss.backward()
+        self._backward(loss)
         self._end_pass()
         return loss
 
@@ -416,7 +424,7 @@ class DataParallelTrainer:
             self._setup(x, gt)
         self._begin_pass(x)
         loss = self.loss_fn(self.model(x), gt)
-        loss.backward()
+        self._backward(loss)
         self._end_pass()
         for h in self._handles:
             h.wait()

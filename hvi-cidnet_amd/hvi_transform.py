@@ -44,7 +44,7 @@ class RGB_HVI(nn.Module):
 
     def HVIT(self, img):
         out = ops.HVITFn.apply(img, self.density_k)
-        self._this_k_dev = self.density_k.detach().clone()      # D2D copy, no host sync
+        self._this_k_dev = ops.snapshot(self.density_k)         # device copy by our own kernel, no host sync
         return out
 
     def PHVIT(self, img):

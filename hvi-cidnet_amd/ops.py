@@ -73,7 +73,7 @@ class HVITFn(torch.autograd.Function):
         g = _c(g)
         need_x, need_k = ctx.needs_input_grad
         gx = torch.empty_like(img) if need_x else None
-        gk = torch.empty_like(k) if need_k else None
+        gk = grad_like(k) if need_k else None                  # the arena slot when density_k has one use per step
         n = lib().raw("cidnet_hvit_bwd_ws_floats")()
         ws = torch.empty(n, device=img.device, dtype=torch.float32) if need_k else None
         lib().call("cidnet_hvit_bwd", _p(img), _p(k), _p(g), _p(gx), _p(gk), _p(ws), n if need_k else 0, B, H, W,
@@ -304,9 +304,11 @@ def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None)
 CONV3_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_BF16X3", "1") == "1"}
 
 
-def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None):
-    """y = conv3x3(x) (+ addend, in the kernel's epilogue; only for layers with more than 4 channels on both sides)"""
-    if CONV3_BF16X3["on"] and not replicate and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
+def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None, x_bs=None):
+    """y = conv3x3(x) (+ addend, in the kernel's epilogue; only for layers with more than 4 channels on both sides).
+    x_bs: batch stride of x in floats when x is a plane slice of a wider tensor (the I stem reads plane 2 of hvi)"""
+    x_bs = K * H * W if x_bs is None else int(x_bs)
+    if CONV3_BF16X3["on"] and not replicate and x_bs == K * H * W and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
             and CONV3_BF16X3.get("filter", lambda *a: True)(M, K, H, W):
         n = _raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)
         ws = _ws(n, x.device)
@@ -314,10 +316,10 @@ def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, add
                    _p(ws), ws.numel(), B, M, K, H, W, _stream())
         return
     if addend is None:
-        lib().call("cidnet_conv3x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
+        lib().call("cidnet_conv3x3", _p(x), x_bs, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
                    H, W, _stream())
     else:
-        lib().call("cidnet_conv3x3_add", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(addend), M * H * W,
+        lib().call("cidnet_conv3x3_add", _p(x), x_bs, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(addend), M * H * W,
                    _p(y), M * H * W, B, M, K, H, W, _stream())
 
 
@@ -326,8 +328,9 @@ def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, add
 CONV3_WGRAD_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_WGRAD_BF16X3", "1") == "1"}
 
 
-def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False):
-    if CONV3_WGRAD_BF16X3["on"] and not replicate and M > 4 and _raw("cidnet_conv3x3_wgrad_bf16x3_supported", M, N, H, W):
+def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False, x_bs=None):
+    x_bs = N * H * W if x_bs is None else int(x_bs)
+    if CONV3_WGRAD_BF16X3["on"] and not replicate and x_bs == N * H * W and M > 4 and _raw("cidnet_conv3x3_wgrad_bf16x3_supported", M, N, H, W):
         n = _raw("cidnet_conv3x3_wgrad_bf16x3_ws_floats", B, M, N, H, W)
         ws = _ws(n, dy.device)
         lib().call("cidnet_conv3x3_wgrad_bf16x3", _p(dy), M * H * W, _p(x), N * H * W, _p(dw), _p(ws), ws.numel(), B, M, N, H, W,
@@ -335,7 +338,7 @@ def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False):
         return
     n = _raw("cidnet_conv3x3_wgrad_ws_floats", B, M, N, H, W)
     ws = _ws(n, dy.device)
-    lib().call("cidnet_conv3x3_wgrad", _p(dy), M * H * W, _p(x), N * H * W, int(replicate), _p(dw), _p(ws), ws.numel(), B, M,
+    lib().call("cidnet_conv3x3_wgrad", _p(dy), M * H * W, _p(x), x_bs, int(replicate), _p(dw), _p(ws), ws.numel(), B, M,
                N, H, W, _stream())
 
 
@@ -848,11 +851,13 @@ class RepConv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         _check(x, w)
-        x = _c(x)
         B, Ci, H, W = x.shape
+        # one plane of a wider tensor (the I stem reads hvi[:, 2:3], net/CIDNet.py:75): read in place through its batch stride
+        if not (Ci == 1 and x.stride(3) == 1 and x.stride(2) == W and x.stride(0) >= H * W):
+            x = _c(x)
         Co = w.shape[0]
         y = torch.empty((B, Co, H, W), device=x.device, dtype=torch.float32)
-        conv3x3(x, w, y, B, Co, Ci, H, W, 9 * Ci, 9, replicate=True)
+        conv3x3(x, w, y, B, Co, Ci, H, W, 9 * Ci, 9, replicate=True, x_bs=x.stride(0))
         ctx.save_for_backward(x, w)
         return y
 
@@ -863,7 +868,7 @@ class RepConv3x3Fn(torch.autograd.Function):
         Co = w.shape[0]
         go = _c(go)
         gw = grad_like(w)
-        _offload_wgrad((go, x, gw), lambda: conv3x3_wgrad(go, x, gw, B, Co, Ci, H, W, replicate=True))
+        _offload_wgrad((go, x, gw), lambda: conv3x3_wgrad(go, x, gw, B, Co, Ci, H, W, replicate=True, x_bs=x.stride(0)))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -919,6 +924,33 @@ class AddFn(torch.autograd.Function):
         return g, g
 
 
+class HviFanoutFn(torch.autograd.Function):
+    """The HVI image feeds three consumers (net/CIDNet.py:73-77,119): the HV stem (whole image), the I stem (plane 2) and
+    the residual of the output.  Returns (hvi, hvi[:, 2:3], hvi) as views; the backward sums the three gradients in ONE
+    kernel (cidnet_hvi_grad_sum) instead of autograd's two accumulation passes plus the slice backward's fill and copy."""
+
+    @staticmethod
+    def forward(ctx, hvi):
+        _check(hvi)
+        hvi = _c(hvi)
+        return hvi.view_as(hvi), hvi[:, 2:3], hvi.view_as(hvi)
+
+    @staticmethod
+    def backward(ctx, ga, gi, gc):
+        ref = ga if ga is not None else gc
+        if ref is None:
+            if gi is None:
+                return None
+            B, _, H, W = gi.shape
+            out = torch.empty((B, 3, H, W), device=gi.device, dtype=torch.float32)
+        else:
+            B, _, H, W = ref.shape
+            out = torch.empty_like(ref, memory_format=torch.contiguous_format)
+        ga, gi, gc = (_c(t) if t is not None else None for t in (ga, gi, gc))
+        lib().call("cidnet_hvi_grad_sum", _p(ga), _p(gc), _p(gi), _p(out), B, H * W, _stream())
+        return out
+
+
 # --------------------------------------------------------------------------------------------
 # training-step pieces: L1 loss (loss + gradient in one pass) and fused flat Adam
 # --------------------------------------------------------------------------------------------
@@ -927,6 +959,15 @@ def _scaled(x, g, mult):
     y = torch.empty_like(x)
     g = g.to(torch.float32).reshape(1).contiguous()
     lib().call("cidnet_scale", _p(x), _p(g), _f(mult), _p(y), x.numel(), _stream())
+    return y
+
+
+def snapshot(t):
+    """detached device copy of a small fp32 tensor through cidnet_scale (keeps ATen's copy kernels out of the step)"""
+    t = t.detach()
+    _check(t)
+    y = torch.empty_like(t)
+    lib().call("cidnet_scale", _p(_c(t)), None, _f(1.0), _p(y), t.numel(), _stream())
     return y
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CIDNET_ABI_VERSION 4
+#define CIDNET_ABI_VERSION 5
 
 int cidnet_abi_version(void);
 
@@ -291,6 +291,10 @@ int cidnet_l1_loss(const float* out, const float* gt, float* grad, float* loss, 
  * backward, and the sign flip that gives the gradient wrt the target (train.py:62: gt_hvi = model.HVIT(gt_rgb)
  * is NOT detached, so density_k receives gradient through the target of every HVI-space term) */
 int cidnet_scale(const float* x, const float* s, float mult, float* y, long n, void* stream);
+/* Gradient of the HVI image at its three-way fan-out (net/CIDNet.py:73-77: `i = hvi[:,2,:,:].unsqueeze(1)` feeds the I stem,
+ * hvi the HV stem; :119 `+ hvi` the output residual): out (B,3,HW) = ga + gc, plane 2 also + gi (B,1,HW).  Null inputs
+ * count as zero.  Replaces autograd's two accumulation passes and the slice backward (fill + copy). */
+int cidnet_hvi_grad_sum(const float* ga, const float* gc, const float* gi, float* out, int B, long HW, void* stream);
 /* SSIM loss ("next" row f1): SSIM.forward, loss/losses.py:166-190 with map_ssim, loss/loss_utils.py:125-145:
  * 11x11 Gaussian window (sigma 1.5), zero padding 5, depthwise; loss = (1 - mean(ssim_map)) * weight (1 float on the
  * device).  dA/dB/dC (B,C,H,W each) are the per-pixel derivative maps the backward filters; ws: block partials.

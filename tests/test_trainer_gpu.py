@@ -220,3 +220,33 @@ def test_trainer_with_reference_objective(dev):
     assert tr.flat_g[:tr.n_live].abs().max().item() > 0
     ops.set_grad_arena(None, None)
     ops.enable_wgrad_stream(False)
+
+
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_training_step_launches_only_cidnet_kernels(dev, two_streams):
+    """beside LDS-fed bf16 MFMAs, packed-fp32 instructions with op_sel in ANOTHER kernel's waves were seen
+    to lose products; libcidnet_hip.so is built without them, ATen's elementwise kernels are not
+    (profiles/r04_a_audit_aten_add_gfx950_packed_fp32.json: v_pk_fma_f32 ... op_sel_hi:[0,1,1] in every
+    vectorized_elementwise_kernel<CUDAFunctor_add<float>>).  So one training step of the shipped configuration -- forward,
+    L1 loss, backward into the arena, fused Adam -- must launch nothing but cidnet:: kernels (at N > 1: plus RCCL's
+    FuncSum kernels, audited in profiles/r04_a_audit_rccl_gfx950_packed_fp32.json): no autograd accumulation adds, no
+    slice copies, no fills, no device-to-device memcpy."""
+    import os
+    import sys
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        from foreign_kernels_in_step import foreign_kernels
+    finally:
+        sys.path.pop(0)
+    chans, shape = (36, 36, 72, 144), (2, 3, 64, 96)
+    x = O.synthetic_batch(41, shape).to(dev)
+    gt = O.synthetic_batch(42, shape).to(dev)
+    m = _model(dev, chans)
+    m.two_streams = two_streams
+    tr = DataParallelTrainer(m, lr=1e-3, wgrad_stream=two_streams)
+    for _ in range(3):
+        tr.step(x, gt)
+    fk = foreign_kernels(tr, x, gt, steps=1)
+    assert not fk, {k: [(op, shp) for op, shp, _ in v][:3] for k, v in fk.items()}
