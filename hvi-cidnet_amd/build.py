@@ -77,9 +77,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
             print(f"[build] linked {LIB} from {len(objs)} objects")
+        _check_code_objects(verbose)
     elif verbose:
         print(f"[build] {LIB} up to date")
     return LIB
+
+
+def _check_code_objects(verbose):
+    """A freshly linked library must pass the static code-object checks (codeobj_check.py: no packed-fp32 / SDWA
+    instructions, no inline-assembly load read before its wait) -- a compiler or flag change (CIDNET_EXTRA_FLAGS) that
+    reintroduces either fails the BUILD, not only a test.  CIDNET_ALLOW_PACKED builds (A/B measurements) skip check 1."""
+    sys.path.insert(0, HERE)
+    try:
+        import codeobj_check
+    finally:
+        sys.path.pop(0)
+    bad, facts = codeobj_check.check_library(LIB, allow_packed=bool(os.environ.get("CIDNET_ALLOW_PACKED")))
+    if bad:
+        os.replace(LIB, LIB + ".rejected")
+        raise RuntimeError("code-object check failed (library moved to %s.rejected):\n  " % LIB + "\n  ".join(bad))
+    if verbose:
+        print(f"[build] code objects clean: {facts}")
 
 
 if __name__ == "__main__":

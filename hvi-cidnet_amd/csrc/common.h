@@ -115,4 +115,22 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Raises a kernel's dynamic-LDS limit (the 64 KB default is below what conv3x / conv3xw / pwb use).  The attribute is per
+// DEVICE, so the "done" flags are indexed by the current device (one static LdsLimit per kernel instantiation); the flag is
+// an atomic and setting the attribute twice is harmless, so two host threads may race here.  Returns the HIP status.
+struct LdsLimit {
+  static constexpr int kMaxDev = 64;
+  unsigned char done[kMaxDev] = {};
+  hipError_t raise(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < kMaxDev;
+    if (cached && __atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && cached) __atomic_store_n(&done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+    return e;
+  }
+};
+
 }  // namespace cidnet

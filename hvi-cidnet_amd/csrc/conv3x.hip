@@ -366,11 +366,8 @@ int launch_conv3x(const float* Wt, long w_ms, long w_ks, int flip, X3Args a, flo
                      reinterpret_cast<uint4*>(ws), total);
   a.tiles_x = (a.W + kXTW - 1) / kXTW;
   a.tiles_y = (a.H + kXTH - 1) / kXTH;
-  static bool attr = false;                                   // idempotent: raises the kernel's dynamic-LDS limit once
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x_kernel<KCH>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-    attr = true;
-  }
+  static LdsLimit lds;                                        // once per device: the kernel's dynamic-LDS limit
+  if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&conv3x_kernel<KCH>), T::LDS_BYTES); e != hipSuccess) return (int)e;
   const long nwork = (long)a.B * a.tiles_x * a.tiles_y * a.mchunks;
   long nblk = 512;                                            // persistent: two resident blocks per CU
   if (nblk > nwork) nblk = nwork;

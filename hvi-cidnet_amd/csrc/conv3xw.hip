@@ -462,11 +462,8 @@ int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, lon
   a.dbg = g_w3_dbg;
 #endif
   const int nblk = w3_blocks_per_pair(B, M, N, H, W);
-  static bool attr = false;                                   // idempotent: raises the kernel's dynamic-LDS limit once
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3xw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWLds);
-    attr = true;
-  }
+  static LdsLimit lds;                                        // once per device: the kernel's dynamic-LDS limit
+  if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&conv3xw_kernel), kWLds); e != hipSuccess) return (int)e;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(conv3xw_kernel, dim3((unsigned)nblk, (unsigned)((M / kWC) * (N / kWC))), dim3(kWThreads), kWLds, s, a);
   CIDNET_LAUNCH_STATUS();

@@ -516,9 +516,10 @@ __global__ __launch_bounds__(kIelThreads, 2) void iel_fwd_kernel(IelArgs a) {
 template <class T>
 int iel_resident() {
   static int cached = 0;                  // idempotent query result, not configuration state
+  static LdsLimit limit;                  // the attribute itself is per device
+  constexpr size_t lds = sizeof(float) * T::LDS_FLOATS;
+  (void)limit.raise(reinterpret_cast<const void*>(&iel_fwd_kernel<T>), (int)lds);
   if (cached == 0) {
-    constexpr size_t lds = sizeof(float) * T::LDS_FLOATS;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&iel_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, iel_fwd_kernel<T>, kIelThreads, lds) != hipSuccess || n < 1) n = 1;
     cached = n;

@@ -313,11 +313,8 @@ int launch_pwb(PwbArgs a, const float* Wt, float* ws, hipStream_t s) {
   hipLaunchKernelGGL(pwb_split_w_kernel, dim3((total + 255) / 256), dim3(256), 0, s, Wt, a.M, a.N, S::KB, wf, total);
   a.wf = wf;
   a.slabs = ws + (long)NT * S::KB * 3 * 64 * 4;
-  static bool attr = false;                                   // idempotent: raises this instantiation's dynamic-LDS limit once
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwb_kernel<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
-    attr = true;
-  }
+  static LdsLimit lds;                                        // once per device: this instantiation's dynamic-LDS limit
+  if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&pwb_kernel<MT, NT>), S::LDS); e != hipSuccess) return -(int)e;   // < 0: HIP error
   const int nblk = pwb_blocks(a.B, a.HW);
   hipLaunchKernelGGL((pwb_kernel<MT, NT>), dim3(nblk), dim3(kBThreads), S::LDS, s, a);
   return nblk;
@@ -362,6 +359,7 @@ int cidnet_pw_bwd_fused(const float* gY, long gy_bs, const float* X, long x_bs, 
   else if (MT == 3 && NT == 6) nblk = launch_pwb<3, 6>(a, Wt, ws, s);
   else if (MT == 3 && NT == 3) nblk = launch_pwb<3, 3>(a, Wt, ws, s);
   else nblk = launch_pwb<5, 3>(a, Wt, ws, s);
+  if (nblk < 0) return -nblk;                                 // the HIP status of the LDS-limit call
   CIDNET_LAUNCH_STATUS();
   const long ne = (long)M * N;
   const long KB = (MT + 1) / 2;
