@@ -40,6 +40,8 @@ def parse():
                     help="storage type of the IEL chain's hidden tensors (arithmetic is fp32 either way); f32 is the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference-leg", action="store_true", help="skip the 32x3x1024x1024 inference measurement (configs[3])")
+    ap.add_argument("--no-prepared-weights", action="store_true", help="A/B: prepare the bf16x3 weight operands per launch (as a plain model(x) call does)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the MSSA / TNSM bs=16 measurement (configs[4])")
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
     ap.add_argument("--op-rows", type=int, default=70, help="rows of the per-shape part of --op-table")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient GEMMs on the branch streams")
@@ -117,15 +119,23 @@ def conv3x3_flops(args):
     return 2.0 * 9 * M * K * H * W * B
 
 
-def conv3x_flops(args):
-    # cidnet_conv3x3_bf16x3(X, x_bs, Wt, w_ms, w_ks, flip, R, r_bs, Y, y_bs, ws, ws_floats, B, M, K, H, W, stream)
-    B, M, K, H, W = args[12], args[13], args[14], args[15], args[16]
+def conv3x_shape(name, args):
+    """(R, B, M, K, H, W) of a dense bf16x3 3x3 launch, either entry point:
+    cidnet_conv3x3_bf16x3(X, x_bs, Wt, w_ms, w_ks, flip, R, r_bs, Y, y_bs, ws, ws_floats, B, M, K, H, W, stream)
+    cidnet_conv3x3_bf16x3_pre(X, x_bs, Wprep, R, r_bs, Y, y_bs, B, M, K, H, W, stream)   (weights prepared once per step)"""
+    if name == "cidnet_conv3x3_bf16x3_pre":
+        return args[3], args[7], args[8], args[9], args[10], args[11]
+    return args[6], args[12], args[13], args[14], args[15], args[16]
+
+
+def conv3x_flops(sh):
+    R, B, M, K, H, W = sh
     return 2.0 * 9 * M * K * H * W * B
 
 
-def conv3x_bytes(args):
+def conv3x_bytes(sh):
     # X (K channels) once + Y (M channels) once (+ the addend R): the compulsory HBM bytes of one launch
-    R, B, M, K, H, W = args[6], args[12], args[13], args[14], args[15], args[16]
+    R, B, M, K, H, W = sh
     return (K + M + (M if R is not None else 0)) * 4.0 * H * W * B
 
 
@@ -138,6 +148,9 @@ def pw_work(name, args):
         return 2.0 * M * K * HW * B, (K * es(x_dt) + M * es(y_dt) + (M * 4 if R is not None else 0)) * HW * B
     if name == "cidnet_pw_conv_bf16x3":   # (X, x_bs, Wt, w_bs, w_ms, w_ks, Y, y_bs, R, r_bs, ws, ws_floats, B, M, K, HW, stream)
         R, B, M, K, HW = args[8], args[12], args[13], args[14], args[15]
+        return 2.0 * M * K * HW * B, (K + M + (M if R is not None else 0)) * 4 * HW * B
+    if name == "cidnet_pw_conv_bf16x3_pre":   # (X, x_bs, Wprep, per_sample, Y, y_bs, R, r_bs, B, M, K, HW, stream)
+        R, B, M, K, HW = args[6], args[8], args[9], args[10], args[11]
         return 2.0 * M * K * HW * B, (K + M + (M if R is not None else 0)) * 4 * HW * B
     if name == "cidnet_pw_conv_up_prelu":  # (skip, x_bs, Wt, w_ms, w_ks, Z, slope, Y, Ypre, B, M, K, zh, zw, stream)
         Ypre, B, M, K, zh, zw = args[8], args[9], args[10], args[11], args[12], args[13]
@@ -209,9 +222,10 @@ def whole_step_roofline(a, ms_per_step):
             "achieved_tflops": round(flops / 1e12 / (ms_per_step * 1e-3), 2)}
 
 
-def inference_1024(dev):
+def inference_1024(dev, world=1, local=0):
     """configs[3]: CIDNet inference on 32x3x1024x1024 (img/s) and the HBM rate of the HVIT / PHVIT kernels on that batch,
-    measured after the timed region (rank 0, one GPU)."""
+    measured after the timed region.  With N ranks every rank runs its own batch (weak scaling, no communication); the
+    line reports the aggregate over the slowest rank's time next to rank 0's own numbers."""
     import hvi_cidnet_amd as P
     from hvi_cidnet_amd import ops
     B, H, W = 32, 1024, 1024
@@ -237,12 +251,57 @@ def inference_1024(dev):
         hvi = ops.HVITFn.apply(x, k)
         ms_h = timeit(lambda: ops.HVITFn.apply(x, k), 10)
         ms_p = timeit(lambda: ops.PHVITFn.apply(hvi, None, None, 0.2, False, 1.3, False, 1.0), 10)
-        ms = timeit(lambda: m(x), 3)
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        # frozen weights: the prepared (split) weight operands are kept across the forward calls (ops.prepared_weights)
+        with ops.prepared_weights(True):
+            ms = timeit(lambda: m(x), 3)
+        ops.clear_prepared_weights()
     del m, x, hvi
     torch.cuda.empty_cache()
-    return {"workload": "CIDNet inference 32x3x1024x1024 fp32 (BASELINE.json configs[3])", "images_per_s": round(B / (ms * 1e-3), 1),
-            "ms_per_batch": round(ms, 2), "hvit_GBs": round(24.0 * px / (ms_h * 1e-3) / 1e9, 1),
+    ms_all = ms
+    if world > 1:
+        t = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_all = t.item()
+    return {"workload": f"CIDNet inference 32x3x1024x1024 fp32 per GPU (BASELINE.json configs[3]), {world} rank(s)",
+            "images_per_s": round(world * B / (ms_all * 1e-3), 1), "n_gpus": world, "ms_per_batch": round(ms_all, 2),
+            "rank0_images_per_s": round(B / (ms * 1e-3), 1), "hvit_GBs": round(24.0 * px / (ms_h * 1e-3) / 1e9, 1),
             "phvit_GBs": round(24.0 * px / (ms_p * 1e-3) / 1e9, 1), "hbm_peak_GBs": PEAK_HBM_GBS, "alg_bytes_per_px": 24}
+
+
+def variants_bs16(dev):
+    """configs[4]: the MSSA and TNSM variants, fwd + L1 (+ 0.1 mean(noise map) for TNSM, so that its noise branch trains) +
+    bwd + fused Adam at bs=16 3x400x600 on one GPU, measured after the timed region (rank 0)."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    from hvi_cidnet_amd import ops
+    B = 16
+    out = {"workload": "CIDNet_MSSA / CIDNet_TNSM fwd+bwd bs=16 3x400x600 fp32 (BASELINE.json configs[4])", "step": "fwd + L1 + bwd + fused Adam"}
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    x = torch.rand((B, 3, 400, 600), device=dev, generator=g)
+    gt = torch.rand((B, 3, 400, 600), device=dev, generator=g)
+    for name, ctor, tnsm in (("CIDNet_MSSA", P.CIDNet_MSSA, False), ("CIDNet_TNSM", P.CIDNet_TNSM, True)):
+        torch.manual_seed(0)
+        m = ctor().to(dev)
+        lf = (lambda y, t: ops.L1LossFn.apply(y[0], t) + 0.1 * y[1].mean()) if tnsm else None
+        tr = DataParallelTrainer(m, lr=1e-4, loss_fn=lf)
+        for _ in range(3):
+            tr.step(x, gt)
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(x, gt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out[name] = {"images_per_s": round(B / dt, 1), "ms_per_step": round(1e3 * dt, 2)}
+        del tr, m
+        ops.set_grad_arena(None, None)
+        ops.clear_prepared_weights()
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -276,7 +335,7 @@ def main():
     model.two_streams = not a.single_stream
     model.dual_norms = a.dual_norms
     trainer = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream),
-                                  use_graph=a.graph, loss_fn=P.CIDNetLoss(model, P_weight=a.p_weight).to(dev) if a.full_loss else None)
+                                  use_graph=a.graph, prepared_weights=not a.no_prepared_weights, loss_fn=P.CIDNetLoss(model, P_weight=a.p_weight).to(dev) if a.full_loss else None)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     shape = (a.batch, 3, a.height, a.width)
@@ -365,7 +424,8 @@ def main():
         c3_flops = sum(conv3x3_flops(ar) for ar, _ in c3)
         c3_ms = sum(ms for _, ms in c3)
         # the same convs on the bf16 matrix cores (csrc/conv3x.hip, the default): six bf16 products per fp32 product
-        cx = [(args, e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if name == "cidnet_conv3x3_bf16x3"]
+        cx = [(conv3x_shape(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
+              if name in ("cidnet_conv3x3_bf16x3", "cidnet_conv3x3_bf16x3_pre")]
         cx_flops = sum(conv3x_flops(ar) for ar, _ in cx)
         cx_ms = sum(ms for _, ms in cx)
         if a.op_table:
@@ -401,7 +461,7 @@ def main():
         # the family that bounds the step: the 1x1 convs and their weight gradients
         pw = [(pw_work(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if pw_work(name, args) is not None]
         pw_fl, pw_by, pw_ms = sum(w[0] for w, _ in pw), sum(w[1] for w, _ in pw), sum(t for _, t in pw)
-        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3, cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t, cidnet_pw_bwd_fused)",
+        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3[_pre], cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t, cidnet_pw_bwd_fused)",
                    "achieved": round(pw_by / (pw_ms * 1e-3) / 1e9, 1) if pw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": round(pw_by / (pw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if pw_ms > 0 else 0.0,
                    "tflops": round(pw_fl / (pw_ms * 1e-3) / 1e12, 2) if pw_ms > 0 else 0.0,
@@ -420,9 +480,18 @@ def main():
                     "traffic": None, "launches_per_step": len(hb) // 2, "alg_gb_per_step": round(hb_bytes / 2 / 1e9, 3),
                     "ms_per_step": round(hb_ms / 2, 3), "storage": a.dtype}
         roof["whole_step"] = whole_step_roofline(a, 1e3 * dt / a.steps)
-        infer = None
-        if world == 1 and not a.no_inference_leg and (a.height, a.width, a.batch) == (400, 600, 8):
-            infer = inference_1024(dev)
+    # the 1024x1024 inference leg runs on EVERY rank (north_star: both sizes at 1/2/4/8 GPUs); the variants on rank 0 at N = 1
+    infer = variants = None
+    default_cfg = (a.height, a.width, a.batch) == (400, 600, 8)
+    if not a.no_inference_leg and default_cfg:
+        del trainer
+        _ops.set_grad_arena(None, None)
+        _ops.clear_prepared_weights()
+        torch.cuda.empty_cache()
+        infer = inference_1024(dev, world, local)
+        if world == 1 and not a.no_variants:
+            variants = variants_bs16(dev)
+    if rank == 0:
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(a)
@@ -438,6 +507,7 @@ def main():
             "roofline": roof if a.dtype == "f32" else dict(roof_hbm, mfma_conv3=roof), "roofline_pw": roof_pw, "roofline_hbm": roof_hbm,
             "cpu_baseline": cpu,
             "inference_1024": infer,
+            "variants_bs16": variants,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -445,7 +515,7 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic_by_family.json"
+PMC_TRAFFIC_FILE = "profiles/r04_d_pmc_traffic_by_family.json"
 
 
 def pmc_traffic(family):

@@ -37,6 +37,7 @@
 // SIMD's only wave; loading a tile's activations in one batch instead of two rounds at a time measured slower too.
 // No packed-fp32 / SDWA instructions: built with -fno-slp-vectorize -mllvm -amdgpu-sdwa-peephole=0.
 #include "common.h"
+#include "cidnet_hip.h"
 
 namespace cidnet {
 namespace {
@@ -96,10 +97,9 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
 // m = 48 mc + 16 mt + r, the eight k of slot s = 4 kb + g: position 8 i + c of the dy-run (dy = s / G, i = s % G), i.e.
 // tap (dy, dx = pos / KCH), input channel kc KCH + pos % KCH; zero past the run, past K's chunk or past M.
 template <int KCH>
-__global__ __launch_bounds__(256) void conv3x_prep_kernel(const float* Wt, long w_ms, long w_ks, int flip, int M, int K,
-                                                          uint4* A, int total) {
+__device__ __forceinline__ void conv3x_prep_item(const float* __restrict__ Wt, long w_ms, long w_ks, int flip, int M, int K,
+                                                 uint4* __restrict__ A, int total, int idx) {
   using T = X3<KCH>;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int lane = idx & 63;
   int f = idx >> 6;
@@ -127,6 +127,31 @@ __global__ __launch_bounds__(256) void conv3x_prep_kernel(const float* Wt, long 
   split3_pair(v[6], v[7], o[0].w, o[1].w, o[2].w);
   uint4* dst = A + ((((long)mc * kchunks + kc) * T::NKB + kb) * 9 + 3 * mt) * 64 + lane;
   dst[0] = o[0]; dst[64] = o[1]; dst[128] = o[2];
+}
+
+template <int KCH>
+__global__ __launch_bounds__(256) void conv3x_prep_kernel(const float* Wt, long w_ms, long w_ks, int flip, int M, int K,
+                                                          uint4* A, int total) {
+  conv3x_prep_item<KCH>(Wt, w_ms, w_ks, flip, M, K, A, total, blockIdx.x * 256 + threadIdx.x);
+}
+
+template <int KCH>
+constexpr int conv3x_prep_total(int M, int K) { return ((M + kXMC - 1) / kXMC) * (K / KCH) * X3<KCH>::NKB * 3 * 64; }
+
+// Many layers in ONE launch (see pwx_split_w_batch_kernel): row r of the table (8 x int64) = source pointer, destination
+// pointer, M, K, w_ms, w_ks, first block of the row, flip.
+constexpr int kPrepRow = 8;
+template <int KCH>
+__global__ __launch_bounds__(256) void conv3x_prep_batch_kernel(const long long* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long)mid * kPrepRow + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* r = table + (long)lo * kPrepRow;
+  const int M = (int)r[2], K = (int)r[3];
+  conv3x_prep_item<KCH>(reinterpret_cast<const float*>(r[0]), r[4], r[5], (int)r[7], M, K, reinterpret_cast<uint4*>(r[1]),
+                        conv3x_prep_total<KCH>(M, K), (int)(((long)blockIdx.x - r[6]) * 256 + threadIdx.x));
 }
 
 // ---- LDS fragment reads as inline asm (see header) ---------------------------------------------------------------------
@@ -354,16 +379,19 @@ __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
 }
 
 template <int KCH>
-int launch_conv3x(const float* Wt, long w_ms, long w_ks, int flip, X3Args a, float* ws, long ws_floats, hipStream_t s) {
+int launch_conv3x_prep(const float* Wt, long w_ms, long w_ks, int flip, int M, int K, float* ws, long ws_floats, hipStream_t s) {
+  const int total = conv3x_prep_total<KCH>(M, K);
+  hipLaunchKernelGGL((conv3x_prep_kernel<KCH>), dim3((total + 255) / 256), dim3(256), 0, s, Wt, w_ms, w_ks, flip, M, K,
+                     reinterpret_cast<uint4*>(ws), total);
+  return CIDNET_OK;
+}
+
+template <int KCH>
+int launch_conv3x(X3Args a, const float* wprep, hipStream_t s) {
   using T = X3<KCH>;
   a.mchunks = (a.M + kXMC - 1) / kXMC;
   a.kchunks = a.K / KCH;
-  const long nfrag4 = (long)a.mchunks * a.kchunks * T::FRAGS * 64;        // uint4 elements
-  if (ws_floats < nfrag4 * 4) return CIDNET_ERR_WS;
-  a.A = reinterpret_cast<const uint4*>(ws);
-  const int total = (int)((long)a.mchunks * a.kchunks * T::NKB * 3 * 64);
-  hipLaunchKernelGGL((conv3x_prep_kernel<KCH>), dim3((total + 255) / 256), dim3(256), 0, s, Wt, w_ms, w_ks, flip, a.M, a.K,
-                     reinterpret_cast<uint4*>(ws), total);
+  a.A = reinterpret_cast<const uint4*>(wprep);
   a.tiles_x = (a.W + kXTW - 1) / kXTW;
   a.tiles_y = (a.H + kXTH - 1) / kXTH;
   static LdsLimit lds;                                        // once per device: the kernel's dynamic-LDS limit
@@ -391,15 +419,48 @@ long cidnet_conv3x3_bf16x3_ws_floats(int M, int K) {
   return (long)((M + kXMC - 1) / kXMC) * (K / 36) * X3<36>::FRAGS * 64 * 4;
 }
 
-int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, const float* R, long r_bs,
-                          float* Y, long y_bs, float* ws, long ws_floats, int B, int M, int K, int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(X && Wt && Y && ws && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
+/* the weight preparation alone: Wt -> ws (split, MFMA fragment order) */
+int cidnet_conv3x3_bf16x3_prep(const float* Wt, long w_ms, long w_ks, int flip, float* ws, long ws_floats, int M, int K, void* stream) {
+  CIDNET_CHECK_ARG(Wt && ws && M > 0 && K > 0);
   if (!cidnet_conv3x3_bf16x3_supported(M, K)) return CIDNET_ERR_SHAPE;
-  X3Args a{X, x_bs, nullptr, R, r_bs, Y, y_bs, B, M, K, H, W, 0, 0, 0, 0, 0};
-  const int rc = launch_conv3x<36>(Wt, w_ms, w_ks, flip, a, ws, ws_floats, (hipStream_t)stream);
+  if (ws_floats < cidnet_conv3x3_bf16x3_ws_floats(M, K)) return CIDNET_ERR_WS;
+  CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+  const int rc = launch_conv3x_prep<36>(Wt, w_ms, w_ks, flip, M, K, ws, ws_floats, (hipStream_t)stream);
   if (rc != CIDNET_OK) return rc;
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+long cidnet_conv3x3_bf16x3_prep_blocks(int M, int K) {
+  return cidnet_conv3x3_bf16x3_supported(M, K) ? (conv3x_prep_total<36>(M, K) + 255) / 256 : 0;
+}
+
+int cidnet_conv3x3_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream) {
+  CIDNET_CHECK_ARG(table && n > 0 && total_blocks > 0);
+  hipLaunchKernelGGL((conv3x_prep_batch_kernel<36>), dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+/* the convolution with weights already prepared by cidnet_conv3x3_bf16x3_prep */
+int cidnet_conv3x3_bf16x3_pre(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y, long y_bs, int B,
+                              int M, int K, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(X && Wprep && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
+  if (!cidnet_conv3x3_bf16x3_supported(M, K)) return CIDNET_ERR_SHAPE;
+  CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(Wprep) & 15) == 0);
+  X3Args a{X, x_bs, nullptr, R, r_bs, Y, y_bs, B, M, K, H, W, 0, 0, 0, 0, 0};
+  const int rc = launch_conv3x<36>(a, Wprep, (hipStream_t)stream);
+  if (rc != CIDNET_OK) return rc;
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, const float* R, long r_bs,
+                          float* Y, long y_bs, float* ws, long ws_floats, int B, int M, int K, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(X && Wt && Y && ws && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
+  const int rc = cidnet_conv3x3_bf16x3_prep(Wt, w_ms, w_ks, flip, ws, ws_floats, M, K, stream);
+  if (rc != CIDNET_OK) return rc;
+  return cidnet_conv3x3_bf16x3_pre(X, x_bs, ws, R, r_bs, Y, y_bs, B, M, K, H, W, stream);
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 //    the fragments of its <= 5 channel tiles for the next k-block right after the MFMA burst that read the current ones.
 // No packed-fp32 / SDWA instructions (hvi-cidnet_amd/build.py).
 #include "common.h"
+#include "cidnet_hip.h"
 #include <type_traits>
 
 namespace cidnet {
@@ -52,9 +53,8 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
 }
 
 // ---- weights -> three bf16 levels in fragment order: fragment (b, kb, mt, level) = 64 lanes x uint4 ----
-__global__ __launch_bounds__(kThreads) void pwx_split_w_kernel(const float* __restrict__ Wt, long w_bs, long w_ms, long w_ks,
-                                                               uint4* __restrict__ Af, int M, int K, int KB, int MT, int nb, int cpg) {
-  const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void pwx_split_w_item(const float* __restrict__ Wt, long w_bs, long w_ms, long w_ks, uint4* __restrict__ Af,
+                                                 int M, int K, int KB, int MT, int nb, int cpg, long idx) {
   const int lane = (int)(idx & 63);
   const long t = idx >> 6;
   if (t >= (long)nb * KB * MT) return;
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(kThreads) void pwx_split_w_kernel(const float* __re
   for (int l = 0; l < 3; ++l) Af[(t * 3 + l) * 64 + lane] = o[l];
 }
 
+__global__ __launch_bounds__(kThreads) void pwx_split_w_kernel(const float* __restrict__ Wt, long w_bs, long w_ms, long w_ks,
+                                                               uint4* __restrict__ Af, int M, int K, int KB, int MT, int nb, int cpg) {
+  pwx_split_w_item(Wt, w_bs, w_ms, w_ks, Af, M, K, KB, MT, nb, cpg, (long)blockIdx.x * kThreads + threadIdx.x);
+}
+
 // Channels per lane group and k-block: 8 (32-channel k-blocks) unless 6 (24-channel k-blocks, two of a lane's eight k-slots
 // zero) needs the same number of k-blocks -- K = 36, 72: 48 / 72 instead of 64 / 96 loaded and split channels, same MFMA
 // count (-9 % at 72 x 72 on 200x300 planes).  K = 144 would take six k-blocks instead of five: slower where M is large.
@@ -83,6 +88,25 @@ __global__ __launch_bounds__(kThreads) void pwx_split_w_kernel(const float* __re
 inline int pwx_cpg(int K) {
   return (PWX_CPG6 && (K + 23) / 24 == (K + 31) / 32) ? 6 : 8;
 }
+
+// Many weight tensors in ONE launch (the trainer refreshes every prepared operand of the step after the optimizer's update
+// instead of ~100 five-microsecond launches spread over the step).  Row r of the table (8 x int64): source pointer,
+// destination pointer, M, K, w_ms, w_ks, first block of the row, unused; a block finds its row by bisection.
+constexpr int kPrepRow = 8;
+__global__ __launch_bounds__(kThreads) void pwx_split_w_batch_kernel(const long long* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                                              // last row whose first block is <= blockIdx.x (uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(long)mid * kPrepRow + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* r = table + (long)lo * kPrepRow;
+  const int M = (int)r[2], K = (int)r[3];
+  const int cpg = (PWX_CPG6 && (K + 23) / 24 == (K + 31) / 32) ? 6 : 8;
+  const int KB = (K + 4 * cpg - 1) / (4 * cpg), MT = (M + 15) / 16;
+  pwx_split_w_item(reinterpret_cast<const float*>(r[0]), 0, r[4], r[5], reinterpret_cast<uint4*>(r[1]), M, K, KB, MT, 1, cpg,
+                   ((long)blockIdx.x - r[6]) * kThreads + threadIdx.x);
+}
+
 
 #ifndef PWX_RINIT
 #define PWX_RINIT 1          // accumulators start as the residual (its loads are the first in flight; no epilogue loads)
@@ -326,22 +350,44 @@ long cidnet_pw_conv_bf16x3_ws_floats(int B, int M, int K, int per_sample) {
   return (per_sample ? (long)B : 1L) * frags * 64 * 4;
 }
 
-int cidnet_pw_conv_bf16x3(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
-                          const float* R, long r_bs, float* ws, long ws_floats, int B, int M, int K, long HW, void* stream) {
-  CIDNET_CHECK_ARG(X && Wt && Y && ws && B > 0);
-  if (!cidnet_pw_conv_bf16x3_supported(M, K, HW)) return CIDNET_ERR_SHAPE;
-  const int per_sample = w_bs != 0;
-  if (ws_floats < cidnet_pw_conv_bf16x3_ws_floats(B, M, K, per_sample)) return CIDNET_ERR_WS;
+/* the split alone: Wt -> ws (fragment order); nb = B for per-sample weights (w_bs != 0), else 1 */
+int cidnet_pw_conv_bf16x3_prep(const float* Wt, long w_bs, long w_ms, long w_ks, float* ws, long ws_floats, int nb, int M, int K,
+                               void* stream) {
+  CIDNET_CHECK_ARG(Wt && ws && nb > 0 && M > 0 && K > 0 && (nb == 1 || w_bs != 0));
+  if (ws_floats < cidnet_pw_conv_bf16x3_ws_floats(nb, M, K, 1)) return CIDNET_ERR_WS;
   CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+  const int cpg = pwx_cpg(K);
+  const int KB = (K + 4 * cpg - 1) / (4 * cpg), MT = (M + 15) / 16;
+  const long threads = (long)nb * KB * MT * 64;
+  hipLaunchKernelGGL(pwx_split_w_kernel, dim3((unsigned)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                     Wt, w_bs, w_ms, w_ks, reinterpret_cast<uint4*>(ws), M, K, KB, MT, nb, cpg);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+long cidnet_pw_conv_bf16x3_prep_blocks(int M, int K) {
+  const int cpg = pwx_cpg(K);
+  const long threads = (long)((K + 4 * cpg - 1) / (4 * cpg)) * ((M + 15) / 16) * 64;
+  return (threads + kThreads - 1) / kThreads;
+}
+
+int cidnet_pw_conv_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream) {
+  CIDNET_CHECK_ARG(table && n > 0 && total_blocks > 0);
+  hipLaunchKernelGGL(pwx_split_w_batch_kernel, dim3((unsigned)total_blocks), dim3(kThreads), 0, (hipStream_t)stream, table, n);
+  CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+/* the product with weights already split by cidnet_pw_conv_bf16x3_prep (Wprep; per_sample: B consecutive sets) */
+int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs, const float* R,
+                              long r_bs, int B, int M, int K, long HW, void* stream) {
+  CIDNET_CHECK_ARG(X && Wprep && Y && B > 0);
+  if (!cidnet_pw_conv_bf16x3_supported(M, K, HW)) return CIDNET_ERR_SHAPE;
+  CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(Wprep) & 15) == 0);
   const PwxPlan p = pwx_plan(M, K, HW);
   hipStream_t s = (hipStream_t)stream;
-  uint4* Af = reinterpret_cast<uint4*>(ws);
-  const int nb = per_sample ? B : 1;
-  const long threads = (long)nb * p.KB * p.MT * 64;
-  hipLaunchKernelGGL(pwx_split_w_kernel, dim3((unsigned)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, Wt, w_bs, w_ms,
-                     w_ks, Af, M, K, p.KB, p.MT, nb, p.cpg);
-  CIDNET_LAUNCH_STATUS();
-  PwxArgs a{X, x_bs, Af, per_sample ? (long)p.KB * p.MT * 3 * 64 : 0L, Y, y_bs, R, r_bs, B, M, K, HW, p.KB, p.MT, p.tiles_per_sample};
+  PwxArgs a{X, x_bs, reinterpret_cast<const uint4*>(Wprep), per_sample ? (long)p.KB * p.MT * 3 * 64 : 0L, Y, y_bs, R, r_bs, B, M, K, HW,
+            p.KB, p.MT, p.tiles_per_sample};
   switch (p.MTW) {
     case 1: launch_pwx<1>(a, p, s); break;
     case 2: launch_pwx<2>(a, p, s); break;
@@ -351,6 +397,16 @@ int cidnet_pw_conv_bf16x3(const float* X, long x_bs, const float* Wt, long w_bs,
   }
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+int cidnet_pw_conv_bf16x3(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
+                          const float* R, long r_bs, float* ws, long ws_floats, int B, int M, int K, long HW, void* stream) {
+  CIDNET_CHECK_ARG(X && Wt && Y && ws && B > 0);
+  if (!cidnet_pw_conv_bf16x3_supported(M, K, HW)) return CIDNET_ERR_SHAPE;
+  const int per_sample = w_bs != 0;
+  const int rc = cidnet_pw_conv_bf16x3_prep(Wt, w_bs, w_ms, w_ks, ws, ws_floats, per_sample ? B : 1, M, K, stream);
+  if (rc != CIDNET_OK) return rc;
+  return cidnet_pw_conv_bf16x3_pre(X, x_bs, ws, per_sample, Y, y_bs, R, r_bs, B, M, K, HW, stream);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 //                    every input pixel sums the output pixels whose 2x2 footprint contains it.
 // All HBM-bound elementwise / small-stencil kernels: lanes run along x for coalesced rows.
 #include "common.h"
+#include "cidnet_hip.h"
 
 namespace cidnet {
 namespace {
@@ -279,19 +280,39 @@ int cidnet_prelu_bwd(const float* dout, const float* pre, const float* slope, fl
 
 long cidnet_bilinear_bwd_ws_floats(int Hi, int Wi) { return 2L * kTabK * ((long)Hi + Wi); }
 
-int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats, int B, int C, int Hi, int Wi, int Ho, int Wo,
-                        void* stream) {
-  CIDNET_CHECK_ARG(dout && din && ws && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
-  if (ws_floats < cidnet_bilinear_bwd_ws_floats(Hi, Wi)) return CIDNET_ERR_WS;
+/* the per-axis tap tables alone (they depend on the four sizes only: a caller may compute them once per shape) */
+int cidnet_bilinear_bwd_tabs(float* tabs, long tabs_floats, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  CIDNET_CHECK_ARG(tabs && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  if (tabs_floats < cidnet_bilinear_bwd_ws_floats(Hi, Wi)) return CIDNET_ERR_WS;
   hipStream_t s = (hipStream_t)stream;
-  int* yidx = reinterpret_cast<int*>(ws);
-  float* ywgt = ws + (long)kTabK * Hi;
-  int* xidx = reinterpret_cast<int*>(ws + 2L * kTabK * Hi);
-  float* xwgt = ws + 2L * kTabK * Hi + (long)kTabK * Wi;
+  int* yidx = reinterpret_cast<int*>(tabs);
+  float* ywgt = tabs + (long)kTabK * Hi;
+  int* xidx = reinterpret_cast<int*>(tabs + 2L * kTabK * Hi);
+  float* xwgt = tabs + 2L * kTabK * Hi + (long)kTabK * Wi;
   hipLaunchKernelGGL(bilinear_tab_kernel, dim3((Hi + 255) / 256), dim3(256), 0, s, yidx, ywgt, Hi, Ho);
   CIDNET_LAUNCH_STATUS();
   hipLaunchKernelGGL(bilinear_tab_kernel, dim3((Wi + 255) / 256), dim3(256), 0, s, xidx, xwgt, Wi, Wo);
   CIDNET_LAUNCH_STATUS();
+  return CIDNET_OK;
+}
+
+int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                        void* stream) {
+  CIDNET_CHECK_ARG(dout && din && ws && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  const int rc = cidnet_bilinear_bwd_tabs(ws, ws_floats, Hi, Wi, Ho, Wo, stream);
+  if (rc != CIDNET_OK) return rc;
+  return cidnet_bilinear_bwd_pre(dout, din, ws, B, C, Hi, Wi, Ho, Wo, stream);
+}
+
+/* the adjoint with tables already computed by cidnet_bilinear_bwd_tabs for the same four sizes */
+int cidnet_bilinear_bwd_pre(const float* dout, float* din, const float* tabs, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                            void* stream) {
+  CIDNET_CHECK_ARG(dout && din && tabs && B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int* yidx = reinterpret_cast<const int*>(tabs);
+  const float* ywgt = tabs + (long)kTabK * Hi;
+  const int* xidx = reinterpret_cast<const int*>(tabs + 2L * kTabK * Hi);
+  const float* xwgt = tabs + 2L * kTabK * Hi + (long)kTabK * Wi;
   // taps of one input index: outputs o with floor(o * s) in {i-1, i}, s = (in-1)/(out-1): at most floor(2/s) + 1
   const double sx = Wo > 1 ? (double)(Wi - 1) / (double)(Wo - 1) : 0.0, sy = Ho > 1 ? (double)(Hi - 1) / (double)(Ho - 1) : 0.0;
   const int kx = sx > 0.0 ? (int)(2.0 / sx + 1e-3) + 1 : kTabK, ky = sy > 0.0 ? (int)(2.0 / sy + 1e-3) + 1 : kTabK;

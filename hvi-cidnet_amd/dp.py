@@ -102,8 +102,10 @@ class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, n_buckets: int = 4, loss_fn: Optional[Callable] = None,
                  process_group=None, use_hip_kernels: bool = True, wgrad_stream: bool = True, use_graph: bool = False,
-                 max_steps_in_flight: int = 3, max_queued_bytes: Optional[int] = None):
+                 max_steps_in_flight: int = 3, max_queued_bytes: Optional[int] = None,
+                 prepared_weights: Optional[bool] = None):
         self.model = model
+        self.prepared_weights = (os.environ.get("CIDNET_PREPARED_WEIGHTS", "1") == "1") if prepared_weights is None else bool(prepared_weights)
         # Back-pressure.  Nothing in a training step synchronises host and device, and the host enqueues a step in ~13 ms
         # while the GPU needs ~31 ms.  Root cause of the multi-second stalls of round 1 (tools/stall_probe.py,
         # profiles/r02_stall_probe_*.txt): every tensor the host frees after it was used on a side stream
@@ -228,6 +230,11 @@ class DataParallelTrainer:
             from . import ops
             ops.set_grad_arena(self.flat_p, self.flat_g, exclude_ptrs=multi)
             ops.enable_wgrad_stream(self.wgrad_stream)
+            # this trainer's fused Adam is the only writer of flat_p: inside its passes (_pass_scope) prepared (split,
+            # fragment-ordered) weight operands are kept across launches, and re-prepared in two launches after every update
+            # (ops.refresh_prepared_weights); anything else that writes the weights without torch's version counter seeing
+            # it (p.data.copy_, raw kernels) must call weights_changed()
+            ops.clear_prepared_weights()
         for p in live:
             p.register_post_accumulate_grad_hook(self._on_grad)
         self.opt = FlatAdam(self.flat_p, kernel=self.use_hip, **self._opt_args)
@@ -341,11 +348,19 @@ class DataParallelTrainer:
             one = self._unit_grad = torch.ones_like(loss)
         loss.backward(gradient=one)
 
+    def _pass_scope(self):
+        if self.use_hip and self.prepared_weights:
+            from . import ops
+            return ops.prepared_weights(True)
+        import contextlib
+        return contextlib.nullcontext()
+
     def _fwd_bwd(self, x, gt):
-        self._begin_pass(x)
-        loss = self.loss_fn(self.model(x), gt)
-        self._backward(loss)
-        self._end_pass()
+        with self._pass_scope():
+            self._begin_pass(x)
+            loss = self.loss_fn(self.model(x), gt)
+            self._backward(loss)
+            self._end_pass()
         return loss
 
     def _capture(self, x, gt):
@@ -382,6 +397,7 @@ class DataParallelTrainer:
         if self.world > 1 or self._force_comm:
             dist.all_reduce(self.flat_g[:self.n_live], op=dist.ReduceOp.SUM, group=self.pg)
         self.opt.step(self.flat_g, self.n_live, grad_scale=1.0 / self.world)
+        self._weights_changed()          # the captured pass reads prepared operands that the eager passes before it created
         return self._gloss
 
     # ---- the step ---------------------------------------------------------------------------------
@@ -406,12 +422,24 @@ class DataParallelTrainer:
                 h.wait()
             self._join_wgrad_stream()
             self.opt.step(self.flat_g, self.n_live, grad_scale=1.0 / self.world)
+            self._weights_changed()
             loss = loss.detach()
         if x.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
             self._step_events.append(ev)
         return loss
+
+    def _weights_changed(self):
+        if self.use_hip and self.prepared_weights and self.flat_p.is_cuda:
+            from . import ops
+            ops.refresh_prepared_weights(self.flat_p.device)
+
+    def weights_changed(self):
+        """call after anything that writes the parameters outside torch's version tracking (p.data.copy_, raw kernels): the
+        prepared weight operands are rebuilt.  load_state_dict / in-place torch ops are seen without it."""
+        if self._ready:
+            self._weights_changed()
 
     @staticmethod
     def _queued_bytes(device):
@@ -422,10 +450,7 @@ class DataParallelTrainer:
         """forward + loss + backward only (gradients left in the flat arena); for timing splits."""
         if not self._ready:
             self._setup(x, gt)
-        self._begin_pass(x)
-        loss = self.loss_fn(self.model(x), gt)
-        self._backward(loss)
-        self._end_pass()
+        loss = self._fwd_bwd(x, gt)
         for h in self._handles:
             h.wait()
         self._join_wgrad_stream()

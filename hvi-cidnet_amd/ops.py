@@ -237,6 +237,130 @@ def _pe(t, off_elems=0):
     return _vp(t.data_ptr() + t.element_size() * int(off_elems))
 
 
+# ---- prepared weight operands kept across calls ------------------------------------------------------------------------
+# The split-product kernels (csrc/pwx.hip, csrc/conv3x.hip) read their weights split into bf16 levels in MFMA fragment
+# order.  Preparing them per call costs a 5 us launch in front of every conv: ~125 per training step (98 shared-weight
+# 1x1 convs, 24 dense 3x3 convs; forward and backward use different orders of the same weights), latency the branch
+# streams cannot hide behind anything.  With the cache ON a prepared operand lives in its own buffer, keyed by (weight
+# address, strides, shape, orientation): the first use prepares it, and whoever changes the weights re-prepares ALL of them
+# in two launches (refresh_prepared_weights: one batched kernel per family) -- dp.DataParallelTrainer does after its fused
+# Adam update, which is the only writer of the flat parameter buffer.  An entry also remembers the tensor's autograd
+# version counter, so in-place updates through torch (load_state_dict, torch.optim) are seen and re-prepared on use;
+# writes through `.data` or raw pointers are not -- hence OFF unless a caller that owns the weight updates turns it on
+# (enable_prepared_weights).  Per-sample operands (the attention maps) are never cached.
+class _Prepared:
+    __slots__ = ("buf", "kind", "row", "version", "tensor")
+
+
+_PREP = {"on": False, "entries": {}, "tables": {}, "stats": [0, 0]}
+_PREP_MAX_ENTRIES = 1024
+
+
+def clear_prepared_weights():
+    if _PREP["entries"] and torch.cuda.is_initialized():
+        torch.cuda.synchronize()                                 # a refresh or a reader may still be in flight
+    _PREP["entries"].clear()
+    _PREP["tables"].clear()
+
+
+def enable_prepared_weights(on=True):
+    """global switch; switching (on or off) drops every cached operand"""
+    clear_prepared_weights()
+    _PREP["on"] = bool(on)
+
+
+class prepared_weights:
+    """`with ops.prepared_weights(True): ...` -- the cache is consulted only inside the block (entries survive it): the
+    trainer wraps its own forward+backward passes, so a model(x) call outside them (validation, a user's own weight
+    surgery between steps) prepares per call as ever."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _PREP["on"]
+        _PREP["on"] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _PREP["on"] = self.prev
+        return False
+
+
+def _prepared(kind, w, w_off, w_ms, w_ks, flip, M, K, n_floats, prepare):
+    """-> buffer holding the prepared operand of weight view (w, w_off, strides), or None with the cache off"""
+    if not _PREP["on"]:
+        return None
+    src = w.data_ptr() + 4 * int(w_off)
+    key = (kind, src, int(w_ms), int(w_ks), int(flip), M, K)
+    e = _PREP["entries"].get(key)
+    ver = w._version
+    if e is not None and e.version == ver:
+        _PREP["stats"][0] += 1
+        return e.buf
+    _PREP["stats"][1] += 1
+    if e is None:
+        if len(_PREP["entries"]) >= _PREP_MAX_ENTRIES:          # weights re-homed over and over: start again
+            _PREP["entries"].clear()
+        e = _Prepared()
+        e.buf = torch.empty(int(n_floats), device=w.device, dtype=torch.float32)
+        e.kind = kind
+        e.row = (src, e.buf.data_ptr(), M, K, int(w_ms), int(w_ks), 0, int(flip))
+        e.tensor = w
+        _PREP["entries"][key] = e
+        _PREP["tables"].pop((kind, w.device), None)
+    e.version = ver
+    prepare(e.buf)
+    return e.buf
+
+
+def refresh_prepared_weights(device=None):
+    """Re-prepare every cached operand from the current weights: one launch per kernel family on the current stream.  For
+    the owner of the weight updates (dp.DataParallelTrainer calls it right after the optimizer step)."""
+    if not _PREP["entries"]:
+        return
+    by = {}
+    for e in _PREP["entries"].values():
+        if device is None or e.buf.device == device:
+            by.setdefault((e.kind, e.buf.device), []).append(e)
+    for (kind, dev), es in by.items():
+        tab = _PREP["tables"].get((kind, dev))
+        if tab is None:
+            blocks_of = lib().raw("cidnet_pw_conv_bf16x3_prep_blocks" if kind == "pw" else "cidnet_conv3x3_bf16x3_prep_blocks")
+            rows, first = [], 0
+            for e in es:
+                r = list(e.row)
+                r[6] = first
+                first += int(blocks_of(r[2], r[3]))
+                rows.append(r)
+            tab = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), first)
+            _PREP["tables"][(kind, dev)] = tab
+        t, n, total = tab
+        with torch.cuda.device(dev):
+            lib().call("cidnet_pw_conv_bf16x3_prep_batch" if kind == "pw" else "cidnet_conv3x3_bf16x3_prep_batch", _p(t), n, total,
+                       _stream())
+        for e in es:
+            e.version = e.tensor._version
+
+
+_BILINEAR_TABS = {}
+
+
+def _bilinear_tabs(device, Hi, Wi, Ho, Wo):
+    """per-axis tap tables of the bilinear adjoint: a function of the four sizes only, computed once per shape and device
+    (they were two 5 us launches in front of each of the 12 adjoint launches of a step)"""
+    key = (device.type, device.index, Hi, Wi, Ho, Wo)
+    t = _BILINEAR_TABS.get(key)
+    if t is None:
+        n = _raw("cidnet_bilinear_bwd_ws_floats", Hi, Wi)
+        t = torch.empty(int(n), device=device, dtype=torch.float32)
+        lib().call("cidnet_bilinear_bwd_tabs", _p(t), t.numel(), Hi, Wi, Ho, Wo, _stream())
+        # the creating stream may not be the one of later users: make the tables globally visible once
+        torch.cuda.current_stream().synchronize()
+        _BILINEAR_TABS[key] = t
+    return t
+
+
 # The 1x1 convs run on the BF16 matrix cores with exact three-way split operands (csrc/pwx.hip, third version: every wave
 # independent, operands split in registers).  It is faster than the fp32-MFMA kernel (pw.hip) on every 1x1 shape of the
 # step but one (tools/sweep_pw_step.py, profiles/r04_b_sweep_pw_step.txt: 1.03 - 2.0x; 3.9 - 4.6 TB/s on the 200x300 planes
@@ -252,6 +376,12 @@ def pw_bf16x3_wins(M, K, HW=0):
 
 def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
     n = _raw("cidnet_pw_conv_bf16x3_ws_floats", B, M, K, int(w_bs != 0))
+    if w_bs == 0 and _PREP["on"]:
+        pre = _prepared("pw", w, w_off, w_ms, w_ks, 0, M, K, n, lambda buf: lib().call(
+            "cidnet_pw_conv_bf16x3_prep", _po(w, w_off), 0, w_ms, w_ks, _p(buf), buf.numel(), 1, M, K, _stream()))
+        lib().call("cidnet_pw_conv_bf16x3_pre", _po(x, x_off), x_bs, _p(pre), 0, _po(y, y_off), y_bs,
+                   _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, _stream())
+        return
     ws = _ws(n, x.device)
     lib().call("cidnet_pw_conv_bf16x3", _po(x, x_off), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _po(y, y_off), y_bs,
                _po(res, r_off) if res is not None else None, r_bs, _p(ws), ws.numel(), B, M, K, HW, _stream())
@@ -311,6 +441,12 @@ def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, add
     if CONV3_BF16X3["on"] and not replicate and x_bs == K * H * W and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
             and CONV3_BF16X3.get("filter", lambda *a: True)(M, K, H, W):
         n = _raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)
+        if _PREP["on"]:
+            pre = _prepared("c3", w, 0, w_ms, w_ks, int(flip), M, K, n, lambda buf: lib().call(
+                "cidnet_conv3x3_bf16x3_prep", _p(w), w_ms, w_ks, int(flip), _p(buf), buf.numel(), M, K, _stream()))
+            lib().call("cidnet_conv3x3_bf16x3_pre", _p(x), K * H * W, _p(pre), _p(addend), M * H * W, _p(y), M * H * W, B, M, K, H, W,
+                       _stream())
+            return
         ws = _ws(n, x.device)
         lib().call("cidnet_conv3x3_bf16x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), _p(addend), M * H * W, _p(y), M * H * W,
                    _p(ws), ws.numel(), B, M, K, H, W, _stream())
@@ -343,9 +479,13 @@ def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False, x_bs=None):
 
 
 def bilinear_bwd(dout, din, B, C, Hi, Wi, Ho, Wo):
-    n = _raw("cidnet_bilinear_bwd_ws_floats", Hi, Wi)
-    ws = _ws(n, dout.device)
-    lib().call("cidnet_bilinear_bwd", _p(dout), _p(din), _p(ws), ws.numel(), B, C, Hi, Wi, Ho, Wo, _stream())
+    if torch.cuda.is_current_stream_capturing():               # no synchronisation inside a capture: tables per call
+        n = _raw("cidnet_bilinear_bwd_ws_floats", Hi, Wi)
+        ws = _ws(n, dout.device)
+        lib().call("cidnet_bilinear_bwd", _p(dout), _p(din), _p(ws), ws.numel(), B, C, Hi, Wi, Ho, Wo, _stream())
+        return
+    tabs = _bilinear_tabs(dout.device, Hi, Wi, Ho, Wo)
+    lib().call("cidnet_bilinear_bwd_pre", _p(dout), _p(din), _p(tabs), B, C, Hi, Wi, Ho, Wo, _stream())
 
 
 def prelu_bwd(go, pre, slope):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CIDNET_ABI_VERSION 5
+#define CIDNET_ABI_VERSION 6
 
 int cidnet_abi_version(void);
 
@@ -123,6 +123,19 @@ int cidnet_pw_conv_bf16x3_supported(int M, int K, long HW);
 long cidnet_pw_conv_bf16x3_ws_floats(int B, int M, int K, int per_sample);
 int cidnet_pw_conv_bf16x3(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, float* Y, long y_bs,
                           const float* R, long r_bs, float* ws, long ws_floats, int B, int M, int K, long HW, void* stream);
+/* The same call in two halves, for callers that keep the prepared weight operand across calls (weights change once per
+ * optimizer step, but are used by a forward and -- transposed -- a backward launch, and by every inference call):
+ * _prep splits Wt into ws (nb sets: B for per-sample weights, w_bs != 0; else 1; ws as above with per_sample = 1 and
+ * B = nb), _pre runs the product from it.  cidnet_pw_conv_bf16x3 == _prep + _pre.  _prep_batch prepares n shared (not
+ * per-sample) weight tensors in ONE launch: `table` is a device array of n rows of 8 x int64 {Wt pointer, ws pointer,
+ * M, K, w_ms, w_ks, first block of the row, 0}; a row takes cidnet_pw_conv_bf16x3_prep_blocks(M, K) blocks, rows in
+ * ascending block order, total_blocks = their sum. */
+int cidnet_pw_conv_bf16x3_prep(const float* Wt, long w_bs, long w_ms, long w_ks, float* ws, long ws_floats, int nb, int M,
+                               int K, void* stream);
+int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs,
+                              const float* R, long r_bs, int B, int M, int K, long HW, void* stream);
+long cidnet_pw_conv_bf16x3_prep_blocks(int M, int K);
+int cidnet_pw_conv_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* Backward of a 1x1 convolution Y = W X (W: (M, N) contiguous) in one kernel: gX (B, N, HW) = W^T gY and dW (M, N) = sum over
  * samples and pixels of gY X^T (overwritten; partial sums combined in fixed order).  gY is read from HBM once instead of once
  * by the data-gradient launch (cidnet_pw_conv* with transposed strides) and once by cidnet_pw_wgrad*.  fp32 tensors, split
@@ -225,6 +238,15 @@ long cidnet_conv3x3_bf16x3_ws_floats(int M, int K);
 int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, const float* R,
                           long r_bs, float* Y, long y_bs, float* ws, long ws_floats, int B, int M, int K, int H,
                           int W, void* stream);
+/* In two halves (see cidnet_pw_conv_bf16x3_prep): _prep writes the prepared weights (flip folded in) to ws, _pre convolves
+ * from them; _prep_batch: rows {Wt pointer, ws pointer, M, K, w_ms, w_ks, first block, flip},
+ * cidnet_conv3x3_bf16x3_prep_blocks(M, K) blocks per row. */
+int cidnet_conv3x3_bf16x3_prep(const float* Wt, long w_ms, long w_ks, int flip, float* ws, long ws_floats, int M, int K,
+                               void* stream);
+int cidnet_conv3x3_bf16x3_pre(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y, long y_bs,
+                              int B, int M, int K, int H, int W, void* stream);
+long cidnet_conv3x3_bf16x3_prep_blocks(int M, int K);
+int cidnet_conv3x3_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
  * NormDownsample when its input also feeds a skip connection (net/CIDNet.py:80-81,85-86): the skip's gradient is
  * added in the epilogue instead of by a separate pass over the tensor.  Layers with <= 4 channels on a side
@@ -263,6 +285,11 @@ int cidnet_prelu_bwd(const float* dout, const float* pre, const float* slope, fl
 long cidnet_bilinear_bwd_ws_floats(int Hi, int Wi);
 int cidnet_bilinear_bwd(const float* dout, float* din, float* ws, long ws_floats, int B, int C, int Hi,
                         int Wi, int Ho, int Wo, void* stream);
+/* In two halves: the per-axis tap tables depend on the four sizes only (cidnet_bilinear_bwd_ws_floats(Hi, Wi) floats), so a
+ * caller may compute them once per shape (_tabs) and run the adjoint from them (_pre). */
+int cidnet_bilinear_bwd_tabs(float* tabs, long tabs_floats, int Hi, int Wi, int Ho, int Wo, void* stream);
+int cidnet_bilinear_bwd_pre(const float* dout, float* din, const float* tabs, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                            void* stream);
 int cidnet_add(const float* a, const float* b, float* y, long n, void* stream);
 
 /* ---- K7: channel attention of CAB  (net/LCA.py:26-38) -------------------------------------------

@@ -513,3 +513,91 @@ def test_pw_conv_bf16x3_split_products(dev, B, M, K, HW, res, form):
     e32 = (y32.cpu().double() - ref).abs().max().item()
     es = (ys.cpu().double() - ref).abs().max().item()
     assert es <= 3 * e32 + 2e-6 * ref.abs().max().item(), (es, e32)
+
+
+def test_prepared_weight_operands_equal_per_call_preparation(dev):
+    """ops.enable_prepared_weights: the split / fragment-ordered weight operands of the bf16x3 1x1 and 3x3 convs kept across
+    calls.  Results are bit-identical to the per-call preparation (cidnet_*_bf16x3 == _prep + _pre); the batched refresh
+    (one launch for all cached operands of a family) equals the individual preparation; a weight changed through torch
+    (version counter) is re-prepared on use, one changed behind torch's back is picked up by refresh_prepared_weights."""
+    from hvi_cidnet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, HW, H, W = 2, 40 * 60, 40, 60
+    pw_shapes = [(36, 95, "fwd"), (72, 36, "dgrad"), (190, 72, "fwd"), (40, 144, "dgrad")]
+    c3_shapes = [(36, 36, 0), (72, 36, 1), (36, 72, 0)]
+    pws = []
+    for M, K, form in pw_shapes:
+        w = torch.randn((M, K) if form == "fwd" else (K, M), device=dev, generator=g) / K ** 0.5
+        pws.append((M, K, w, (K, 1) if form == "fwd" else (1, M), torch.randn(B, K, HW, device=dev, generator=g)))
+    c3s = []
+    for M, K, flip in c3_shapes:
+        w = torch.randn((K, M, 3, 3) if flip else (M, K, 3, 3), device=dev, generator=g) / (3 * K ** 0.5)
+        c3s.append((M, K, flip, w, (9, 9 * M) if flip else (9 * K, 9), torch.randn(B, K, H, W, device=dev, generator=g)))
+
+    def run_all():
+        outs = []
+        for M, K, w, (ms, ks), x in pws:
+            y = torch.full((B, M, HW), float("nan"), device=dev)
+            ops.pw_conv_bf16x3(x, 0, K * HW, w, 0, 0, ms, ks, y, 0, M * HW, B, M, K, HW)
+            outs.append(y)
+        for M, K, flip, w, (ms, ks), x in c3s:
+            y = torch.full((B, M, H, W), float("nan"), device=dev)
+            ops.conv3x3(x, w, y, B, M, K, H, W, ms, ks, flip=bool(flip))
+            outs.append(y)
+        return outs
+
+    def same(a, b):
+        return all(torch.equal(p, q) for p, q in zip(a, b))
+    old = dict(ops.CONV3_BF16X3)
+    ops.CONV3_BF16X3["on"] = True
+    try:
+        ops.enable_prepared_weights(False)
+        ref = run_all()
+        ops.enable_prepared_weights(True)
+        first = run_all()                       # every operand prepared on first use
+        assert ops._PREP["stats"][1] >= len(pws) + len(c3s)
+        hits0 = ops._PREP["stats"][0]
+        again = run_all()                       # all hits
+        assert ops._PREP["stats"][0] - hits0 == len(pws) + len(c3s)
+        assert same(ref, first) and same(ref, again)
+        # in-place update through torch: seen by the version counter
+        pws[0][2].mul_(1.5)
+        c3s[1][3].add_(0.01)
+        ops.enable_prepared_weights(False)
+        ref2 = run_all()
+        ops.enable_prepared_weights(True)
+        run_all()
+        keep = pws[0][2].clone(), c3s[1][3].clone()
+        pws[0][2].mul_(0.3); c3s[1][3].sub_(0.02)                # changed while cached ...
+        assert not same(ref2, run_all())
+        pws[0][2].copy_(keep[0]); c3s[1][3].copy_(keep[1])       # ... and back (in-place: the version counter moves)
+        assert same(ref2, run_all())
+        assert not same(ref, ref2)
+        # a write behind torch's back (raw kernel on the buffer, as the fused Adam does): stale until the refresh
+        for t in (pws[1][2], pws[2][2], c3s[0][3], c3s[2][3]):
+            ops.lib().call("cidnet_scale", ops._p(t), None, ops._f(0.5), ops._p(t), t.numel(), ops._stream())
+        stale = run_all()
+        assert same(stale, ref2)
+        ops.refresh_prepared_weights(dev if isinstance(dev, torch.device) else torch.device(dev))
+        fresh = run_all()
+        ops.enable_prepared_weights(False)
+        ref3 = run_all()
+        assert same(fresh, ref3) and not same(ref3, ref2)
+    finally:
+        ops.enable_prepared_weights(False)
+        ops.CONV3_BF16X3.update(old)
+
+
+def test_bilinear_tables_once_per_shape(dev):
+    """cidnet_bilinear_bwd == _tabs + _pre; ops.bilinear_bwd keeps the tap tables per shape"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    for (B, C, Hi, Wi, Ho, Wo) in [(2, 5, 16, 24, 8, 12), (1, 7, 10, 15, 20, 30), (2, 3, 50, 75, 100, 150)]:
+        g = rnd(7, (B, C, Ho, Wo)).to(dev)
+        a, b2 = torch.full((B, C, Hi, Wi), float("nan"), device=dev), torch.full((B, C, Hi, Wi), float("nan"), device=dev)
+        n = ops._raw("cidnet_bilinear_bwd_ws_floats", Hi, Wi)
+        ws = torch.empty(n, device=dev)
+        lib().call("cidnet_bilinear_bwd", ops._p(g), ops._p(a), ops._p(ws), ws.numel(), B, C, Hi, Wi, Ho, Wo, ops._stream())
+        ops.bilinear_bwd(g, b2, B, C, Hi, Wi, Ho, Wo)
+        ops.bilinear_bwd(g, b2, B, C, Hi, Wi, Ho, Wo)
+        assert torch.equal(a, b2)

@@ -250,3 +250,33 @@ def test_training_step_launches_only_cidnet_kernels(dev, two_streams):
         tr.step(x, gt)
     fk = foreign_kernels(tr, x, gt, steps=1)
     assert not fk, {k: [(op, shp) for op, shp, _ in v][:3] for k, v in fk.items()}
+
+
+def test_trainer_prepared_weights_bit_identical(dev):
+    """DataParallelTrainer(prepared_weights=True): the bf16x3 convs read weight operands prepared once per optimizer step
+    (two batched launches after the fused Adam) instead of once per launch -- parameters after three steps are bit-identical
+    to the per-call preparation, and the cache is actually hit"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    chans, shape = (36, 36, 72, 144), (2, 3, 64, 96)
+    x = O.synthetic_batch(41, shape).to(dev)
+    gt = O.synthetic_batch(42, shape).to(dev)
+    finals = []
+    try:
+        for prepared in (False, True):
+            m = _model(dev, chans)
+            tr = DataParallelTrainer(m, lr=1e-3, prepared_weights=prepared)
+            ops._PREP["stats"][:] = [0, 0]
+            for _ in range(3):
+                tr.step(x, gt)
+            torch.cuda.synchronize()
+            finals.append(tr.flat_p.clone())
+            if prepared:
+                hits, misses = ops._PREP["stats"]
+                assert misses > 50 and hits >= 2 * misses - 10, (hits, misses)    # prepared in the first pass, reused afterwards
+                assert not ops._PREP["on"]             # the cache is consulted inside the trainer's passes only
+        assert torch.equal(finals[0], finals[1])
+    finally:
+        ops.enable_prepared_weights(False)
+        ops.set_grad_arena(None, None)
+        ops.enable_wgrad_stream(False)
