@@ -123,7 +123,7 @@ def conv3x_shape(name, args):
     """(R, B, M, K, H, W) of a dense bf16x3 3x3 launch, either entry point:
     cidnet_conv3x3_bf16x3(X, x_bs, Wt, w_ms, w_ks, flip, R, r_bs, Y, y_bs, ws, ws_floats, B, M, K, H, W, stream)
     cidnet_conv3x3_bf16x3_pre(X, x_bs, Wprep, R, r_bs, Y, y_bs, B, M, K, H, W, stream)   (weights prepared once per step)"""
-    if name == "cidnet_conv3x3_bf16x3_pre":
+    if name in ("cidnet_conv3x3_bf16x3_pre", "cidnet_conv3x3_bf16x3_pre_lv"):
         return args[3], args[7], args[8], args[9], args[10], args[11]
     return args[6], args[12], args[13], args[14], args[15], args[16]
 
@@ -149,7 +149,7 @@ def pw_work(name, args):
     if name == "cidnet_pw_conv_bf16x3":   # (X, x_bs, Wt, w_bs, w_ms, w_ks, Y, y_bs, R, r_bs, ws, ws_floats, B, M, K, HW, stream)
         R, B, M, K, HW = args[8], args[12], args[13], args[14], args[15]
         return 2.0 * M * K * HW * B, (K + M + (M if R is not None else 0)) * 4 * HW * B
-    if name == "cidnet_pw_conv_bf16x3_pre":   # (X, x_bs, Wprep, per_sample, Y, y_bs, R, r_bs, B, M, K, HW, stream)
+    if name in ("cidnet_pw_conv_bf16x3_pre", "cidnet_pw_conv_bf16x3_pre_lv"):   # (X, x_bs, Wprep, per_sample, Y, y_bs, R, r_bs, B, M, K, HW, [w_levels, x_levels,] stream)
         R, B, M, K, HW = args[6], args[8], args[9], args[10], args[11]
         return 2.0 * M * K * HW * B, (K + M + (M if R is not None else 0)) * 4 * HW * B
     if name == "cidnet_pw_conv_up_prelu":  # (skip, x_bs, Wt, w_ms, w_ks, Z, slope, Y, Ypre, B, M, K, zh, zw, stream)
@@ -329,7 +329,7 @@ def main():
     cpus = pin_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # per-rank CPU slice (N > 1 only)
     if cpus is not None:
         print(f"[bench] rank {rank}: pinned to {len(cpus)} CPUs ({cpus[0]}..{cpus[-1]})", file=sys.stderr)
-    P.set_storage_dtype(a.dtype)
+    P.set_precision(a.dtype)
     torch.manual_seed(0)
     model = P.CIDNet().to(dev)
     model.two_streams = not a.single_stream
@@ -425,7 +425,7 @@ def main():
         c3_ms = sum(ms for _, ms in c3)
         # the same convs on the bf16 matrix cores (csrc/conv3x.hip, the default): six bf16 products per fp32 product
         cx = [(conv3x_shape(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec
-              if name in ("cidnet_conv3x3_bf16x3", "cidnet_conv3x3_bf16x3_pre")]
+              if name in ("cidnet_conv3x3_bf16x3", "cidnet_conv3x3_bf16x3_pre", "cidnet_conv3x3_bf16x3_pre_lv")]
         cx_flops = sum(conv3x_flops(ar) for ar, _ in cx)
         cx_ms = sum(ms for _, ms in cx)
         if a.op_table:
@@ -437,10 +437,11 @@ def main():
         if cx_ms > c3_ms:
             # fp32-equivalent (algorithmic) rate, and the rate of the bf16 MFMA work it issues for it against the dense bf16 peak
             eq = cx_flops / (cx_ms * 1e-3) / 1e12
+            nprod = 6 if _ops.MATH["levels"] == 3 else 1
             roof = {"bound": "mfma", "kernel": "conv3x_kernel (cidnet_conv3x3_bf16x3: dense 3x3 fwd + dgrad as six exact bf16 "
                                                "products per fp32 product on v_mfma_f32_16x16x32_bf16)",
-                    "achieved": round(6 * eq, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(6 * eq / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "achieved": round(nprod * eq, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(nprod * eq / PEAK_BF16_MFMA_TFLOPS, 4), "bf16_products_per_term": nprod,
                     "fp32_equivalent_tflops": round(eq, 2), "vs_fp32_mfma_peak": round(eq / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": pmc_traffic("conv3x"), "traffic_source": PMC_TRAFFIC_FILE,
                     "alg_bytes_per_launch": int(sum(conv3x_bytes(ar) for ar, _ in cx) / max(len(cx), 1)),
@@ -501,7 +502,7 @@ def main():
                       + " + bwd + grad all-reduce + Adam)",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if a.dtype == "f32" else "bf16 storage of the IEL hidden tensors, f32 arithmetic", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if a.dtype == "f32" else "bf16 (matrix-core operands rounded to bf16, fp32 accumulation; bf16 storage of the LCA-internal tensors)", "data": "synthetic",
             "config": {"workload": f"CIDNet fwd+bwd bs={a.batch}/GPU 3x{a.height}x{a.width} fp32 (BASELINE.json configs[1])",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
             "roofline": roof if a.dtype == "f32" else dict(roof_hbm, mfma_conv3=roof), "roofline_pw": roof_pw, "roofline_hbm": roof_hbm,

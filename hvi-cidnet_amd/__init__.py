@@ -17,7 +17,7 @@ from .transformer_utils import LayerNorm, NormDownsample, NormUpsample
 from .losses import L1Loss, SSIM, EdgeLoss, CIDNetLoss, PerceptualLoss, VGGFeatureExtractor, tnsm_noise_loss
 from .inference import enhance, load_weights, save_pretrained, pad_to_multiple
 from .schedule import WarmupCosineLR
-from .ops import set_storage_dtype
+from .ops import set_storage_dtype, set_precision, set_math_levels
 
 __all__ = ["CIDNet", "CIDNet_MSSA", "SpatialAttention", "CIDNet_TNSM", "HV_TNSM", "I_TNSM", "TrainableNoiseSuppression", "RGB_HVI", "CAB", "IEL", "HV_LCA", "I_LCA", "LayerNorm", "NormDownsample", "NormUpsample", "L1Loss", "SSIM", "EdgeLoss", "CIDNetLoss", "tnsm_noise_loss", "PerceptualLoss", "VGGFeatureExtractor", "enhance", "load_weights", "save_pretrained", "pad_to_multiple",
-           "WarmupCosineLR", "set_storage_dtype"]
+           "WarmupCosineLR", "set_storage_dtype", "set_precision", "set_math_levels"]

@@ -40,6 +40,17 @@ def disassemble(co, symbolize=False):
     return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
 
 
+def kernel_symbols(dis, substring):
+    """names of the function symbols of a disassembly that contain `substring` (one per template instantiation)"""
+    import re
+    names = []
+    for m in re.finditer(r"^(?:[0-9a-f]+ )?<([\w.$]+)>:$", dis, flags=re.M):
+        n = m.group(1)
+        if substring in n and not n.startswith(("L", ".L")) and n not in names:
+            names.append(n)
+    return names
+
+
 def check_library(lib_path, allow_packed=False):
     """-> (violations, facts): violations is a list of strings (empty = clean), facts counts what was looked at"""
     if not os.path.exists(OBJDUMP):
@@ -59,11 +70,12 @@ def check_library(lib_path, allow_packed=False):
                     bad.append(f"{os.path.basename(co)}: {len(hits)} packed-fp32 / SDWA instructions, e.g. {hits[0]}")
             if "conv3xw_kernel" in dis:
                 sym = disassemble(co, symbolize=True)
-                nloads, hz = _hazard_checker().check(sym, "conv3xw_kernel")
-                facts["asm_loads_checked"] += nloads
-                if nloads < 8:
-                    bad.append(f"conv3xw_kernel: only {nloads} inline-assembly loads found (expected >= 8)")
-                bad += [f"conv3xw_kernel: load destination touched before its wait: {h}" for h in hz[:4]]
+                for name in kernel_symbols(sym, "conv3xw_kernel"):         # every instantiation (operand levels 3 and 1)
+                    nloads, hz = _hazard_checker().check(sym, name)
+                    facts["asm_loads_checked"] += nloads
+                    if nloads < 8:
+                        bad.append(f"{name}: only {nloads} inline-assembly loads found (expected >= 8)")
+                    bad += [f"{name}: load destination touched before its wait: {h}" for h in hz[:4]]
     if facts["code_objects"] < 15:
         bad.append(f"only {facts['code_objects']} gfx950 code objects found in {lib_path}")
     if facts["asm_loads_checked"] == 0:

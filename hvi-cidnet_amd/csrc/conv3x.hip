@@ -64,7 +64,8 @@ struct X3 {
   static constexpr int NKB = (SLOTS + 3) / 4;               // k-blocks (MFMAs deep) per input-channel chunk
   static constexpr int RP = x3_row_pitch(KCH);              // halfs per staged row
   static constexpr int LEVEL_BYTES = kXPH * RP * 2;
-  static constexpr int LDS_BYTES = 3 * LEVEL_BYTES;
+  static constexpr int LDS_BYTES = 3 * LEVEL_BYTES;         // three activation levels (XL = 3); XL levels in general
+  static constexpr int lds_bytes(int xl) { return xl * LEVEL_BYTES; }
   static constexpr int FRAGS = NKB * 9;                     // uint4-per-lane fragments per (channel chunk, input chunk)
   static_assert(KCH % 4 == 0, "pixels must stay 8-byte aligned");
   static_assert(2 * LEVEL_BYTES + 2 * RP * 2 + G * 16 + 3 * KCH * 2 < 65536, "ds_read offset field");
@@ -158,11 +159,11 @@ __global__ __launch_bounds__(256) void conv3x_prep_batch_kernel(const long long*
 typedef unsigned long long u64;
 #define X3_DSREAD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 
-template <int KCH>
-struct BSet { u64 v[6]; };             // [level][half]
+template <int KCH, int XL>
+struct BSet { u64 v[2 * XL]; };        // [level][half]
 
-template <int KCH>
-__device__ __forceinline__ void b_issue(BSet<KCH>& s, unsigned addr, const int e) {
+template <int KCH, int XL>
+__device__ __forceinline__ void b_issue(BSet<KCH, XL>& s, unsigned addr, const int e) {
   using T = X3<KCH>;
   // `e` is a compile-time constant at every call site (fully unrolled): the offsets fold into the instruction
   switch (e) {
@@ -170,21 +171,33 @@ __device__ __forceinline__ void b_issue(BSet<KCH>& s, unsigned addr, const int e
     case E:                                                            \
       X3_DSREAD(s.v[0], addr, E * KCH * 2);                            \
       X3_DSREAD(s.v[1], addr, E * KCH * 2 + 8);                        \
-      X3_DSREAD(s.v[2], addr, E * KCH * 2 + T::LEVEL_BYTES);           \
-      X3_DSREAD(s.v[3], addr, E * KCH * 2 + T::LEVEL_BYTES + 8);       \
-      X3_DSREAD(s.v[4], addr, E * KCH * 2 + 2 * T::LEVEL_BYTES);       \
-      X3_DSREAD(s.v[5], addr, E * KCH * 2 + 2 * T::LEVEL_BYTES + 8);   \
+      if constexpr (XL > 1) {                                          \
+        X3_DSREAD(s.v[2], addr, E * KCH * 2 + T::LEVEL_BYTES);         \
+        X3_DSREAD(s.v[3], addr, E * KCH * 2 + T::LEVEL_BYTES + 8);     \
+      }                                                                \
+      if constexpr (XL > 2) {                                          \
+        X3_DSREAD(s.v[4], addr, E * KCH * 2 + 2 * T::LEVEL_BYTES);     \
+        X3_DSREAD(s.v[5], addr, E * KCH * 2 + 2 * T::LEVEL_BYTES + 8); \
+      }                                                                \
       break;
     X3_CASE(0) X3_CASE(1) X3_CASE(2) X3_CASE(3)
 #undef X3_CASE
   }
 }
 
-// wait until at most `N` of this wave's LDS reads are outstanding; the set's registers are "produced" here, so no
-// consumer can be scheduled above the wait
-#define X3_WAIT(N, s)                                                                                         \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                   \
-               : "+v"((s).v[0]), "+v"((s).v[1]), "+v"((s).v[2]), "+v"((s).v[3]), "+v"((s).v[4]), "+v"((s).v[5]))
+// wait until at most the NEXT set's reads (2 XL of them; `next` = false: none) are outstanding; the set's registers are
+// "produced" here, so no consumer can be scheduled above the wait
+template <int KCH, int XL>
+__device__ __forceinline__ void b_wait(BSet<KCH, XL>& s, const bool next) {
+  if constexpr (XL == 3) {
+    if (next) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]));
+  } else {
+    static_assert(XL == 1, "activation levels: 1 or 3");
+    if (next) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(s.v[0]), "+v"(s.v[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s.v[0]), "+v"(s.v[1]));
+  }
+}
 
 __device__ __forceinline__ bf16x8 frag_of(u64 lo, u64 hi) {
   const uint4 q = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
@@ -199,17 +212,22 @@ __device__ __attribute__((noinline)) void store_ragged(float* yp, const float* r
   if (cnt > 2) yp[2] = v2 + (rp ? rp[2] : 0.f);
 }
 
-template <int KCH>
+// WL / XL: bf16 levels of the weights / activations that enter the products (all pairs i + j <= 2, small terms first).
+// (3, 3): six products = the fp32 product to fp32 rounding (the parity mode).  (1, 1): both operands rounded to nearest
+// bf16, one product -- the arithmetic of a bf16 autocast conv with fp32 accumulation and fp32 output; the staging pass then
+// converts instead of splitting (1 VALU op per pair instead of 11) and the tile takes a third of the LDS.  (3, 1): exact
+// weights, rounded activations, three products.
+template <int KCH, int WL, int XL>
 __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
   using T = X3<KCH>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];       // [3][PH][RP] bf16
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];       // [XL][PH][RP] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int H = a.H, W = a.W, M = a.M;
   const long HW = (long)H * W;
 
   // the row pads (run overrun of a row's last pixel) are read with zero weights: they must hold finite values
-  for (int i = tid; i < T::LDS_BYTES / 16; i += kXThreads) reinterpret_cast<uint4*>(xs)[i] = uint4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < T::lds_bytes(XL) / 16; i += kXThreads) reinterpret_cast<uint4*>(xs)[i] = uint4{0u, 0u, 0u, 0u};
 
   // this lane's byte offset of slot 4 kb + g inside a pixel's three runs
   unsigned soff[T::NKB];
@@ -288,13 +306,19 @@ __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
             for (int j = 0; j < 4; ++j) {
               const int lc = 4 * q + j - 3;                  // column inside the staged tile
               if (lc < 0 || lc >= kXPW) continue;
-              unsigned p0a, p1a, p2a, p0b, p1b, p2b;
-              split3_pair(v[0][j], v[1][j], p0a, p1a, p2a);
-              split3_pair(v[2][j], v[3][j], p0b, p1b, p2b);
               unsigned char* dst = xs + (ry * T::RP + lc * KCH + 4 * cg) * 2;
-              *reinterpret_cast<uint2*>(dst) = uint2{p0a, p0b};
-              *reinterpret_cast<uint2*>(dst + T::LEVEL_BYTES) = uint2{p1a, p1b};
-              *reinterpret_cast<uint2*>(dst + 2 * T::LEVEL_BYTES) = uint2{p2a, p2b};
+              if constexpr (XL == 1) {
+                const unsigned pa = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0][j], v[1][j]}, bf16x2));
+                const unsigned pb = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2][j], v[3][j]}, bf16x2));
+                *reinterpret_cast<uint2*>(dst) = uint2{pa, pb};
+              } else {
+                unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+                split3_pair(v[0][j], v[1][j], p0a, p1a, p2a);
+                split3_pair(v[2][j], v[3][j], p0b, p1b, p2b);
+                *reinterpret_cast<uint2*>(dst) = uint2{p0a, p0b};
+                *reinterpret_cast<uint2*>(dst + T::LEVEL_BYTES) = uint2{p1a, p1b};
+                *reinterpret_cast<uint2*>(dst + 2 * T::LEVEL_BYTES) = uint2{p2a, p2b};
+              }
             }
           }
         }
@@ -303,47 +327,51 @@ __global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
 
       // ---- compute: 3 channel tiles x 4 N-tiles per wave, NKB k-blocks ----
       const uint4* Ab = a.A + ((long)mc * a.kchunks + kc) * (T::FRAGS * 64) + lane;
-      uint4 an[9];
+      // weight fragments of a k-block: [mt][level] in the prepared layout; only the first WL levels are fetched
+      uint4 an[3][WL];
 #pragma unroll
-      for (int f = 0; f < 9; ++f) an[f] = Ab[f * 64];
-      BSet<KCH> s0, s1;
-      b_issue<KCH>(s0, pbase + soff[0], 0);
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int l = 0; l < WL; ++l) an[mt][l] = Ab[(3 * mt + l) * 64];
+      BSet<KCH, XL> s0, s1;
+      b_issue<KCH, XL>(s0, pbase + soff[0], 0);
 #pragma unroll
       for (int kb = 0; kb < T::NKB; ++kb) {
-        bf16x8 af[9];
+        bf16x8 af[3][WL];
 #pragma unroll
-        for (int f = 0; f < 9; ++f) af[f] = __builtin_bit_cast(bf16x8, an[f]);
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+          for (int l = 0; l < WL; ++l) af[mt][l] = __builtin_bit_cast(bf16x8, an[mt][l]);
         if (kb + 1 < T::NKB) {
 #pragma unroll
-          for (int f = 0; f < 9; ++f) an[f] = Ab[((kb + 1) * 9 + f) * 64];
+          for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int l = 0; l < WL; ++l) an[mt][l] = Ab[((kb + 1) * 9 + 3 * mt + l) * 64];
         }
         const unsigned addr = pbase + soff[kb];
         const unsigned addr_next = pbase + soff[kb + 1 < T::NKB ? kb + 1 : kb];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          BSet<KCH>& cur = (e & 1) ? s1 : s0;
-          BSet<KCH>& nxt = (e & 1) ? s0 : s1;
+          BSet<KCH, XL>& cur = (e & 1) ? s1 : s0;
+          BSet<KCH, XL>& nxt = (e & 1) ? s0 : s1;
           const bool more = e < 3 || kb + 1 < T::NKB;
           if (more) {
-            if (e < 3) b_issue<KCH>(nxt, addr, e + 1); else b_issue<KCH>(nxt, addr_next, 0);
-            X3_WAIT(6, cur);
-          } else {
-            X3_WAIT(0, cur);
+            if (e < 3) b_issue<KCH, XL>(nxt, addr, e + 1); else b_issue<KCH, XL>(nxt, addr_next, 0);
           }
-          const bf16x8 b0 = frag_of(cur.v[0], cur.v[1]), b1 = frag_of(cur.v[2], cur.v[3]), b2 = frag_of(cur.v[4], cur.v[5]);
-          // smallest terms first; the three channel tiles interleave, so dependent MFMAs are three issues apart
+          b_wait<KCH, XL>(cur, more);
+          bf16x8 bl[XL];
 #pragma unroll
-          for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3 * mt + 2], b0, acc[mt][e], 0, 0, 0);
+          for (int l = 0; l < XL; ++l) bl[l] = frag_of(cur.v[2 * l], cur.v[2 * l + 1]);
+          // smallest terms first (level sums 2, 1, 0); the three channel tiles interleave, so dependent MFMAs are three
+          // issues apart
 #pragma unroll
-          for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3 * mt + 1], b1, acc[mt][e], 0, 0, 0);
+          for (int sum = 2; sum >= 0; --sum)
 #pragma unroll
-          for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3 * mt + 0], b2, acc[mt][e], 0, 0, 0);
+            for (int i = sum; i >= 0; --i) {                      // weight level i, activation level sum - i
+              if (i >= WL || sum - i >= XL) continue;
 #pragma unroll
-          for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3 * mt + 1], b0, acc[mt][e], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3 * mt + 0], b1, acc[mt][e], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3 * mt + 0], b0, acc[mt][e], 0, 0, 0);
+              for (int mt = 0; mt < 3; ++mt) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][i], bl[sum - i], acc[mt][e], 0, 0, 0);
+            }
         }
       }
     }
@@ -386,7 +414,7 @@ int launch_conv3x_prep(const float* Wt, long w_ms, long w_ks, int flip, int M, i
   return CIDNET_OK;
 }
 
-template <int KCH>
+template <int KCH, int WL, int XL>
 int launch_conv3x(X3Args a, const float* wprep, hipStream_t s) {
   using T = X3<KCH>;
   a.mchunks = (a.M + kXMC - 1) / kXMC;
@@ -394,13 +422,14 @@ int launch_conv3x(X3Args a, const float* wprep, hipStream_t s) {
   a.A = reinterpret_cast<const uint4*>(wprep);
   a.tiles_x = (a.W + kXTW - 1) / kXTW;
   a.tiles_y = (a.H + kXTH - 1) / kXTH;
+  constexpr int lds_bytes = T::lds_bytes(XL);
   static LdsLimit lds;                                        // once per device: the kernel's dynamic-LDS limit
-  if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&conv3x_kernel<KCH>), T::LDS_BYTES); e != hipSuccess) return (int)e;
+  if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&conv3x_kernel<KCH, WL, XL>), lds_bytes); e != hipSuccess) return (int)e;
   const long nwork = (long)a.B * a.tiles_x * a.tiles_y * a.mchunks;
   long nblk = 512;                                            // persistent: two resident blocks per CU
   if (nblk > nwork) nblk = nwork;
   a.stagger = 2;                                              // ~8k cycles: about the length of a staging phase
-  hipLaunchKernelGGL((conv3x_kernel<KCH>), dim3((unsigned)nblk), dim3(kXThreads), T::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv3x_kernel<KCH, WL, XL>), dim3((unsigned)nblk), dim3(kXThreads), lds_bytes, s, a);
   return CIDNET_OK;
 }
 
@@ -442,17 +471,27 @@ int cidnet_conv3x3_bf16x3_prep_batch(const long long* table, int n, long total_b
   return CIDNET_OK;
 }
 
-/* the convolution with weights already prepared by cidnet_conv3x3_bf16x3_prep */
-int cidnet_conv3x3_bf16x3_pre(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y, long y_bs, int B,
-                              int M, int K, int H, int W, void* stream) {
+/* the convolution with weights already prepared by cidnet_conv3x3_bf16x3_prep; w_levels / x_levels: bf16 levels of the
+ * weights / activations that enter the products -- (3, 3) the fp32-exact six products, (3, 1) and (1, 1) the bf16 modes */
+int cidnet_conv3x3_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y, long y_bs,
+                                 int B, int M, int K, int H, int W, int w_levels, int x_levels, void* stream) {
   CIDNET_CHECK_ARG(X && Wprep && Y && B > 0 && M > 0 && K > 0 && H > 0 && W > 0);
   if (!cidnet_conv3x3_bf16x3_supported(M, K)) return CIDNET_ERR_SHAPE;
   CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(Wprep) & 15) == 0);
   X3Args a{X, x_bs, nullptr, R, r_bs, Y, y_bs, B, M, K, H, W, 0, 0, 0, 0, 0};
-  const int rc = launch_conv3x<36>(a, Wprep, (hipStream_t)stream);
+  int rc;
+  if (w_levels == 3 && x_levels == 3) rc = launch_conv3x<36, 3, 3>(a, Wprep, (hipStream_t)stream);
+  else if (w_levels == 3 && x_levels == 1) rc = launch_conv3x<36, 3, 1>(a, Wprep, (hipStream_t)stream);
+  else if (w_levels == 1 && x_levels == 1) rc = launch_conv3x<36, 1, 1>(a, Wprep, (hipStream_t)stream);
+  else return CIDNET_ERR_ARG;
   if (rc != CIDNET_OK) return rc;
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
+}
+
+int cidnet_conv3x3_bf16x3_pre(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y, long y_bs, int B,
+                              int M, int K, int H, int W, void* stream) {
+  return cidnet_conv3x3_bf16x3_pre_lv(X, x_bs, Wprep, R, r_bs, Y, y_bs, B, M, K, H, W, 3, 3, stream);
 }
 
 int cidnet_conv3x3_bf16x3(const float* X, long x_bs, const float* Wt, long w_ms, long w_ks, int flip, const float* R, long r_bs,

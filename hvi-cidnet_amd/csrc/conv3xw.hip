@@ -30,6 +30,7 @@
 //    kernel sums the slabs in fixed order into dW's (co, ci, dy, dx) layout.
 // No packed-fp32 / SDWA instructions (hvi-cidnet_amd/build.py).
 #include "common.h"
+#include "cidnet_hip.h"
 
 namespace cidnet {
 namespace {
@@ -91,86 +92,95 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsi
 // transposing LDS read: per 16-lane group, lane 4 q + p supplies the address of (row q, four 16-bit columns 4 p .. 4 p + 3);
 // lane i receives column i of the four rows.  EXEC must be all ones (no divergence around these reads).
 #define W3_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define W3_WAIT6(N, s)                                                                                       \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                   \
-               : "+v"((s)[0]), "+v"((s)[1]), "+v"((s)[2]), "+v"((s)[3]), "+v"((s)[4]), "+v"((s)[5]))
+// wait until at most the NEXT fragment set's reads (2 LV of them; `next` = false: none) are outstanding
+template <int LV>
+__device__ __forceinline__ void frag_wait(u64 (&s)[2 * LV], const bool next) {
+  if constexpr (LV == 3) {
+    if (next) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]));
+  } else {
+    static_assert(LV == 1, "operand levels: 1 or 3");
+    if (next) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(s[0]), "+v"(s[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]));
+  }
+}
 
 __device__ __forceinline__ bf16x8 frag_of(u64 lo, u64 hi) {
   const uint4 q = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
   return __builtin_bit_cast(bf16x8, q);
 }
 
-// the six transposing reads of one fragment triple (3 levels x 2 halves of the 32-pixel depth) at byte offset OFF
-template <int OFF, int LEVEL>
-__device__ __forceinline__ void frag_issue(u64 (&s)[6], unsigned addr) {
+// the transposing reads of one fragment set (LV levels x 2 halves of the 32-pixel depth) at byte offset OFF
+template <int OFF, int LEVEL, int LV>
+__device__ __forceinline__ void frag_issue(u64 (&s)[2 * LV], unsigned addr) {
   W3_TR(s[0], addr, OFF);
   W3_TR(s[1], addr, OFF + 4 * kWPix);
-  W3_TR(s[2], addr, OFF + LEVEL);
-  W3_TR(s[3], addr, OFF + LEVEL + 4 * kWPix);
-  W3_TR(s[4], addr, OFF + 2 * LEVEL);
-  W3_TR(s[5], addr, OFF + 2 * LEVEL + 4 * kWPix);
+  if constexpr (LV > 1) {
+    W3_TR(s[2], addr, OFF + LEVEL);
+    W3_TR(s[3], addr, OFF + LEVEL + 4 * kWPix);
+  }
+  if constexpr (LV > 2) {
+    W3_TR(s[4], addr, OFF + 2 * LEVEL);
+    W3_TR(s[5], addr, OFF + 2 * LEVEL + 4 * kWPix);
+  }
 }
 
 // One tile row R (of the wave's two) of a rectangular part of the product: row tiles RT0 .. RT0 + RTN - 1, column tiles
 // CT0 .. CT0 + CTN - 1, accumulators acc[ACC0 + ct * RTN + rt].  A fragments (dY) stay in registers for the row, B fragments
 // (X) are read one column tile ahead of their MFMAs.
-template <int RT0, int RTN, int CT0, int CTN, int ACC0, int R>
+template <int RT0, int RTN, int CT0, int CTN, int ACC0, int R, int LV>
 __device__ __forceinline__ void part_row(f32x4 (&acc)[13], const unsigned (&aA)[kWT], const unsigned (&aB)[kWT]) {
-  u64 af[RTN][6];
+  u64 af[RTN][2 * LV];
 #pragma unroll
-  for (int rt = 0; rt < RTN; ++rt) frag_issue<R * kWYRow, kWYLevel>(af[rt], aA[RT0 + rt]);
-  u64 s0[6], s1[6];
-  frag_issue<R * kWXRow, kWXLevel>(s0, aB[CT0]);
-  bf16x8 a0[RTN], a1[RTN], a2[RTN];
+  for (int rt = 0; rt < RTN; ++rt) frag_issue<R * kWYRow, kWYLevel, LV>(af[rt], aA[RT0 + rt]);
+  u64 s0[2 * LV], s1[2 * LV];
+  frag_issue<R * kWXRow, kWXLevel, LV>(s0, aB[CT0]);
+  bf16x8 al[RTN][LV];
 #pragma unroll
   for (int ct = 0; ct < CTN; ++ct) {
-    u64 (&cs)[6] = (ct & 1) ? s1 : s0;
-    u64 (&nx)[6] = (ct & 1) ? s0 : s1;
-    if (ct + 1 < CTN) {
-      frag_issue<R * kWXRow, kWXLevel>(nx, aB[CT0 + (ct + 1 < CTN ? ct + 1 : ct)]);
-      W3_WAIT6(6, cs);
-    } else {
-      W3_WAIT6(0, cs);
-    }
+    u64 (&cs)[2 * LV] = (ct & 1) ? s1 : s0;
+    u64 (&nx)[2 * LV] = (ct & 1) ? s0 : s1;
+    if (ct + 1 < CTN) frag_issue<R * kWXRow, kWXLevel, LV>(nx, aB[CT0 + (ct + 1 < CTN ? ct + 1 : ct)]);
+    frag_wait<LV>(cs, ct + 1 < CTN);
     if (ct == 0) {                                           // issued before s0: landed
 #pragma unroll
       for (int rt = 0; rt < RTN; ++rt) {
-        asm volatile("" : "+v"(af[rt][0]), "+v"(af[rt][1]), "+v"(af[rt][2]), "+v"(af[rt][3]), "+v"(af[rt][4]), "+v"(af[rt][5]));
-        a0[rt] = frag_of(af[rt][0], af[rt][1]); a1[rt] = frag_of(af[rt][2], af[rt][3]); a2[rt] = frag_of(af[rt][4], af[rt][5]);
+        if constexpr (LV == 3) asm volatile("" : "+v"(af[rt][0]), "+v"(af[rt][1]), "+v"(af[rt][2]), "+v"(af[rt][3]), "+v"(af[rt][4]), "+v"(af[rt][5]));
+        else asm volatile("" : "+v"(af[rt][0]), "+v"(af[rt][1]));
+#pragma unroll
+        for (int l = 0; l < LV; ++l) al[rt][l] = frag_of(af[rt][2 * l], af[rt][2 * l + 1]);
       }
     }
-    const bf16x8 b0 = frag_of(cs[0], cs[1]), b1 = frag_of(cs[2], cs[3]), b2 = frag_of(cs[4], cs[5]);
+    bf16x8 bl[LV];
+#pragma unroll
+    for (int l = 0; l < LV; ++l) bl[l] = frag_of(cs[2 * l], cs[2 * l + 1]);
     f32x4* c = &acc[ACC0 + ct * RTN];
-    // small terms first
+    // small terms first: level sums 2, 1, 0 (a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0 with three levels; a0 b0 with one)
 #pragma unroll
-    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[rt], b0, c[rt], 0, 0, 0);
+    for (int sum = 2; sum >= 0; --sum)
 #pragma unroll
-    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b1, c[rt], 0, 0, 0);
+      for (int i = sum; i >= 0; --i) {
+        if (i >= LV || sum - i >= LV) continue;
 #pragma unroll
-    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b2, c[rt], 0, 0, 0);
-#pragma unroll
-    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[rt], b0, c[rt], 0, 0, 0);
-#pragma unroll
-    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b1, c[rt], 0, 0, 0);
-#pragma unroll
-    for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[rt], b0, c[rt], 0, 0, 0);
+        for (int rt = 0; rt < RTN; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][i], bl[sum - i], c[rt], 0, 0, 0);
+      }
   }
 }
 
 // the four groups' parts of the 7 x 7 product: 4x3, 4x3, 3x4 and 3x3 + 4x1 tiles.  The group is a template parameter of the
 // whole MFMA-wave loop: with the four variants in one loop body the register allocator shuffled the accumulators between
 // the variants' assignments and spilled.
-template <int GRP, int R>
+template <int GRP, int R, int LV>
 __device__ __forceinline__ void group_row(f32x4 (&acc)[13], const unsigned (&aA)[kWT], const unsigned (&aB)[kWT]) {
   if (GRP == 0) {
-    part_row<0, 4, 0, 3, 0, R>(acc, aA, aB);
+    part_row<0, 4, 0, 3, 0, R, LV>(acc, aA, aB);
   } else if (GRP == 1) {
-    part_row<0, 4, 3, 3, 0, R>(acc, aA, aB);
+    part_row<0, 4, 3, 3, 0, R, LV>(acc, aA, aB);
   } else if (GRP == 2) {
-    part_row<4, 3, 0, 4, 0, R>(acc, aA, aB);
+    part_row<4, 3, 0, 4, 0, R, LV>(acc, aA, aB);
   } else {
-    part_row<4, 3, 4, 3, 0, R>(acc, aA, aB);
-    part_row<0, 4, 6, 1, 9, R>(acc, aA, aB);
+    part_row<4, 3, 4, 3, 0, R, LV>(acc, aA, aB);
+    part_row<0, 4, 6, 1, 9, R, LV>(acc, aA, aB);
   }
 }
 
@@ -239,6 +249,7 @@ __device__ __forceinline__ void units_wait(f32x4 (&q)[kWRounds][4]) {
                  "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[2][3]), "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]), "+v"(q[3][3]));
 }
 
+template <int LV>
 __device__ __forceinline__ void unit_write(const Unit& t, const f32x4 (&q)[4], int fix, unsigned char* buf, int dbg = 0) {
   if (!t.live) return;
   float v[16];                                               // [channel][pixel]
@@ -270,17 +281,23 @@ __device__ __forceinline__ void unit_write(const Unit& t, const f32x4 (&q)[4], i
   for (int j = 0; j < 4; ++j) {
     const int lc = t.isx ? t.col + j : t.col + j + 1;        // column inside the staged tile
     if (lc < 0 || lc >= (t.isx ? kWTW : kWYCols)) continue;
-    unsigned p0a, p1a, p2a, p0b, p1b, p2b;
-    split3_pair(v[j], v[4 + j], p0a, p1a, p2a);
-    split3_pair(v[8 + j], v[12 + j], p0b, p1b, p2b);
     unsigned char* dst = base + j * kWPix;
-    *reinterpret_cast<uint2*>(dst) = uint2{p0a, p0b};
-    *reinterpret_cast<uint2*>(dst + lvl) = uint2{p1a, p1b};
-    *reinterpret_cast<uint2*>(dst + 2 * lvl) = uint2{p2a, p2b};
+    if constexpr (LV == 1) {                                   // one level: round to nearest bf16 (same tile geometry, level 0 only)
+      const unsigned pa = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[j], v[4 + j]}, bf16x2));
+      const unsigned pb = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[8 + j], v[12 + j]}, bf16x2));
+      *reinterpret_cast<uint2*>(dst) = uint2{pa, pb};
+    } else {
+      unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+      split3_pair(v[j], v[4 + j], p0a, p1a, p2a);
+      split3_pair(v[8 + j], v[12 + j], p0b, p1b, p2b);
+      *reinterpret_cast<uint2*>(dst) = uint2{p0a, p0b};
+      *reinterpret_cast<uint2*>(dst + lvl) = uint2{p1a, p1b};
+      *reinterpret_cast<uint2*>(dst + 2 * lvl) = uint2{p2a, p2b};
+    }
   }
 }
 
-template <int GRP>
+template <int GRP, int LV>
 __device__ __forceinline__ void mma_waves(const W3Args& a, unsigned char* xs, int kh, int lane, int nt) {
   const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
   // this lane's transposing-read addresses in tile buffer 0: k = pixel 8 g + q of a tile row (+ 4 for the second half)
@@ -301,8 +318,8 @@ __device__ __forceinline__ void mma_waves(const W3Args& a, unsigned char* xs, in
   __syncthreads();
   for (int p = 0; p < nt; ++p) {
     if (!W3_DBG(2)) {
-      group_row<GRP, 0>(acc, aA, aB);
-      group_row<GRP, 1>(acc, aA, aB);
+      group_row<GRP, 0, LV>(acc, aA, aB);
+      group_row<GRP, 1, LV>(acc, aA, aB);
     }
     if (!W3_DBG(1)) {                                        // the next tile is in the other buffer
       const unsigned d = (p & 1) ? (unsigned)-kWBuf : (unsigned)kWBuf;
@@ -338,6 +355,9 @@ __device__ __forceinline__ void mma_waves(const W3Args& a, unsigned char* xs, in
   }
 }
 
+// LV: bf16 levels of BOTH operands that enter the products: 3 = six products, the fp32-exact parity mode; 1 = operands rounded
+// to nearest bf16, one product (bf16 autocast arithmetic with fp32 accumulation; the staging waves convert instead of split)
+template <int LV>
 __global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
       if (wr) {
         unsigned char* wbuf = xs + (((p + 1) & 1) && !W3_DBG(1) ? kWBuf : 0);
 #pragma unroll
-        for (int r = 0; r < kWRounds; ++r) unit_write(un[r], pq[r], fix[r], wbuf, W3_DBG(8));
+        for (int r = 0; r < kWRounds; ++r) unit_write<LV>(un[r], pq[r], fix[r], wbuf, W3_DBG(8));
       }
       int jl = p + 2;
       jl = jl >= nt ? nt - 1 : jl;                           // past the block's range: a valid tile, loaded and not used
@@ -389,10 +409,10 @@ __global__ __launch_bounds__(kWThreads, 1) void conv3xw_kernel(W3Args a) {
   }
 
   const int grp = wave & 3, kh = wave >> 2;
-  if (grp == 0) mma_waves<0>(a, xs, kh, lane, nt);
-  else if (grp == 1) mma_waves<1>(a, xs, kh, lane, nt);
-  else if (grp == 2) mma_waves<2>(a, xs, kh, lane, nt);
-  else mma_waves<3>(a, xs, kh, lane, nt);
+  if (grp == 0) mma_waves<0, LV>(a, xs, kh, lane, nt);
+  else if (grp == 1) mma_waves<1, LV>(a, xs, kh, lane, nt);
+  else if (grp == 2) mma_waves<2, LV>(a, xs, kh, lane, nt);
+  else mma_waves<3, LV>(a, xs, kh, lane, nt);
 }
 
 // dW[co][ci][dy][dx] = sum over the nslab slabs of the chunk pair (co / 36, ci / 36) of slab[36 dx + co % 36][36 dy + ci % 36].
@@ -454,7 +474,13 @@ long cidnet_conv3x3_wgrad_bf16x3_ws_floats(int B, int M, int N, int H, int W) {
 
 int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws, long ws_floats,
                                 int B, int M, int N, int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && H > 0 && W > 0);
+  return cidnet_conv3x3_wgrad_bf16x3_lv(dY, dy_bs, X, x_bs, dW, ws, ws_floats, B, M, N, H, W, 3, stream);
+}
+
+/* levels: bf16 levels of both operands that enter the products: 3 (six products, fp32-exact) or 1 (one product) */
+int cidnet_conv3x3_wgrad_bf16x3_lv(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws, long ws_floats,
+                                   int B, int M, int N, int H, int W, int levels, void* stream) {
+  CIDNET_CHECK_ARG(dY && X && dW && ws && B > 0 && M > 0 && N > 0 && H > 0 && W > 0 && (levels == 1 || levels == 3));
   if (!cidnet_conv3x3_wgrad_bf16x3_supported(M, N, H, W)) return CIDNET_ERR_SHAPE;
   if (ws_floats < cidnet_conv3x3_wgrad_bf16x3_ws_floats(B, M, N, H, W)) return CIDNET_ERR_WS;
   W3Args a{dY, dy_bs, X, x_bs, ws, B, M, N, H, W, (W + kWTW - 1) / kWTW, (H + kWTH - 1) / kWTH, N / kWC};
@@ -462,10 +488,16 @@ int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, lon
   a.dbg = g_w3_dbg;
 #endif
   const int nblk = w3_blocks_per_pair(B, M, N, H, W);
-  static LdsLimit lds;                                        // once per device: the kernel's dynamic-LDS limit
-  if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&conv3xw_kernel), kWLds); e != hipSuccess) return (int)e;
+  static LdsLimit lds3, lds1;                                 // once per device: the kernels' dynamic-LDS limit
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3xw_kernel, dim3((unsigned)nblk, (unsigned)((M / kWC) * (N / kWC))), dim3(kWThreads), kWLds, s, a);
+  const dim3 grid((unsigned)nblk, (unsigned)((M / kWC) * (N / kWC)));
+  if (levels == 3) {
+    if (const hipError_t e = lds3.raise(reinterpret_cast<const void*>(&conv3xw_kernel<3>), kWLds); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv3xw_kernel<3>, grid, dim3(kWThreads), kWLds, s, a);
+  } else {
+    if (const hipError_t e = lds1.raise(reinterpret_cast<const void*>(&conv3xw_kernel<1>), kWLds); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv3xw_kernel<1>, grid, dim3(kWThreads), kWLds, s, a);
+  }
   CIDNET_LAUNCH_STATUS();
   const int npairs = (M / kWC) * (N / kWC);
   hipLaunchKernelGGL(conv3xw_reduce_kernel, dim3((unsigned)((npairs * kWSlab + 31) / 32)), dim3(256), 0, s, ws, nblk, npairs, N, a.nchunks, dW);

@@ -789,6 +789,12 @@ typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
 
 // eight fp32 values (this lane's eight consecutive pixels of one row = the eight k of its lane group in a 16x16x32 MFMA)
 // -> the row's fragment at three bf16 levels, v = l0 + l1 + l2 exactly (round to nearest, every remainder exact)
+// one level: the eight values rounded to nearest bf16
+__device__ __forceinline__ uint4 wg_round8(const f32x4& lo, const f32x4& hi) {
+  auto pair = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{x, y}, wg_bf16x2)); };
+  return uint4{pair(lo[0], lo[1]), pair(lo[2], lo[3]), pair(hi[0], hi[1]), pair(hi[2], hi[3])};
+}
+
 __device__ __forceinline__ void wg_split8(const f32x4& lo, const f32x4& hi, uint4 (&f)[3]) {
   auto pair = [](float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
     const wg_bf16x2 h0 = __builtin_convertvector(wg_f32x2{x, y}, wg_bf16x2);
@@ -809,7 +815,9 @@ __device__ __forceinline__ void wg_split8(const f32x4& lo, const f32x4& hi, uint
 // BF3: the products run on the BF16 matrix cores as six exact bf16 cross products per fp32 product (see conv3x.hip): a
 // lane's eight consecutive pixels of a row ARE its 16x16x32 fragment, so the loads do not change; 6 MFMAs of 16 cycles
 // replace 8 of 32 per tile pair and step, at 11 VALU instructions per loaded pixel pair for the split.
-template <int MT, int NT, class DT, bool BF3 = false>       // DT::X = type of dY, DT::Y = type of X
+// LV = 3: that; LV = 1: both operands rounded to nearest bf16, ONE product (the bf16 mode: bf16 autocast arithmetic with fp32
+// accumulation; any storage types); LV = 0: the fp32 MFMA.
+template <int MT, int NT, class DT, int LV = 0>             // DT::X = type of dY, DT::Y = type of X
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
   extern __shared__ float red[];                 // [4 waves][MT*NT*4 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -865,7 +873,19 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { bc[nt][0] = bv[nt][0]; bc[nt][1] = bv[nt][1]; }
     if (p + 128 < pend) load_step(p + 128);       // prefetch this wave's next 32-pixel step
-    if constexpr (BF3) {
+    if constexpr (LV == 1) {
+      uint4 af[MT], bf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = wg_round8(ac[mt][0], ac[mt][1]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = wg_round8(bc[nt][0], bc[nt][1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, af[mt]), __builtin_bit_cast(wg_bf16x8, bf[nt]),
+                                                                acc[mt][nt], 0, 0, 0);
+    } else if constexpr (LV == 3) {
       uint4 af[MT][3], bf[NT][3];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) wg_split8(ac[mt][0], ac[mt][1], af[mt]);
@@ -951,7 +971,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 template <int MT, int NT, class DT>
 int launch_wg_dt(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
   dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnb), (unsigned)B);
-  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, DT>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
+  if (a.bf3 == 1) hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, DT, 1>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, DT>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
@@ -959,9 +980,9 @@ int launch_wg_dt(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
 // instantiated type pairs (dY, X): all fp32; a bf16 hidden tensor on either side
 template <int MT, int NT>
 int launch_wg(const WgArgs& a, int chunks, int nmb, int B, hipStream_t s) {
-  if (a.ddt == 0 && a.xdt == 0 && a.bf3) {
+  if (a.ddt == 0 && a.xdt == 0 && a.bf3 == 3) {
     dim3 grid((unsigned)chunks, (unsigned)(nmb * a.nnb), (unsigned)B);
-    hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, PwDT<0, 0>, true>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
+    hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, PwDT<0, 0>, 3>), grid, dim3(kThreads), (size_t)MT * NT * 4 * 64 * 4 * sizeof(float), s, a);
     CIDNET_LAUNCH_STATUS();
     return CIDNET_OK;
   }
@@ -1067,7 +1088,7 @@ int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int 
   WgArgs a{};
   a.dY = dY; a.dy_bs = dy_bs; a.ddt = dy_dt; a.X = X; a.x_bs = x_bs; a.xdt = x_dt; a.slabs = ws; a.M = M; a.N = N; a.HW = HW;
   a.pch = wgrad_pch(B, M, N, HW);
-  a.bf3 = (flags & CIDNET_WGRAD_FP32_MFMA) ? 0 : 1;
+  a.bf3 = (flags & CIDNET_WGRAD_FP32_MFMA) ? 0 : (flags & CIDNET_WGRAD_BF16_1LEVEL) ? 1 : 3;   // operand levels (0: fp32 MFMA)
   const int accumulate = flags & CIDNET_WGRAD_ACCUMULATE;
   const int chunks = (int)((HW + a.pch - 1) / a.pch);
   const int MT = pick_tiles(M, 3), NT = pick_tiles(N, 3);

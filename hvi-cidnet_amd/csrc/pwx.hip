@@ -118,7 +118,11 @@ __global__ __launch_bounds__(kThreads) void pwx_split_w_batch_kernel(const long 
 #define PWX_MAX_MTW 5
 #endif
 
-template <int MTW, int WM, int CPG>
+// WL / XL: bf16 levels of the weights / activations that enter the products (all pairs i + j <= 2, small terms first):
+// (3, 3) the fp32-exact six products (parity mode); (1, 1) both operands rounded to nearest bf16, one product (the
+// arithmetic of a bf16 autocast conv, fp32 accumulation and output), the activations converted instead of split;
+// (3, 1) exact weights, rounded activations.
+template <int MTW, int WM, int CPG, int WL, int XL>
 __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
   constexpr int NG = 4 / WM;                                     // pixel groups per block
   constexpr int NP = CPG / 2;                                    // channel pairs = non-zero dwords of a B fragment
@@ -167,13 +171,14 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
   for (int j = 0; j < MTW; ++j) mts[j] = min(mt0 + j, a.MT - 1);
 
   const unsigned uHW = (unsigned)HW, upq = (unsigned)pq;         // K * HW < 2^31 (supported()): 32-bit element offsets
-  uint4 A[MTW][3];
+  uint4 A[MTW][WL];
   auto load_a = [&](int kb) {
     const uint4* Ak = Au + (long)kb * a.MT * (3 * 64);
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
       const uint4* Am = Ak + (long)mts[j] * (3 * 64);
-      A[j][0] = Am[lane]; A[j][1] = Am[64 + lane]; A[j][2] = Am[128 + lane];
+#pragma unroll
+      for (int l = 0; l < WL; ++l) A[j][l] = Am[l * 64 + lane];
     }
   };
   auto load_raw = [&](f32x4 (&raw)[CPG], int kb) {
@@ -184,39 +189,48 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
     }
   };
   // B fragments of the four N-tiles, three levels each: dword q of a fragment = channel pair q of the lane group
-  uint4 bf[4][3];
+  uint4 bf[4][XL];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int l = 0; l < 3; ++l) bf[e][l] = uint4{0u, 0u, 0u, 0u};
+    for (int l = 0; l < XL; ++l) bf[e][l] = uint4{0u, 0u, 0u, 0u};
+  auto cvt_pair = [](float p, float q) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{p, q}, bf16x2)); };
   auto split_raw = [&](f32x4 (&raw)[CPG]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      split3_pair(raw[0][e], raw[1][e], bf[e][0].x, bf[e][1].x, bf[e][2].x);
-      split3_pair(raw[2][e], raw[3][e], bf[e][0].y, bf[e][1].y, bf[e][2].y);
-      if constexpr (NP > 2) split3_pair(raw[4][e], raw[5][e], bf[e][0].z, bf[e][1].z, bf[e][2].z);
-      if constexpr (NP > 3) split3_pair(raw[6][e], raw[7][e], bf[e][0].w, bf[e][1].w, bf[e][2].w);
+      if constexpr (XL == 1) {
+        bf[e][0].x = cvt_pair(raw[0][e], raw[1][e]);
+        bf[e][0].y = cvt_pair(raw[2][e], raw[3][e]);
+        if constexpr (NP > 2) bf[e][0].z = cvt_pair(raw[4][e], raw[5][e]);
+        if constexpr (NP > 3) bf[e][0].w = cvt_pair(raw[6][e], raw[7][e]);
+      } else {
+        split3_pair(raw[0][e], raw[1][e], bf[e][0].x, bf[e][1].x, bf[e][2].x);
+        split3_pair(raw[2][e], raw[3][e], bf[e][0].y, bf[e][1].y, bf[e][2].y);
+        if constexpr (NP > 2) split3_pair(raw[4][e], raw[5][e], bf[e][0].z, bf[e][1].z, bf[e][2].z);
+        if constexpr (NP > 3) split3_pair(raw[6][e], raw[7][e], bf[e][0].w, bf[e][1].w, bf[e][2].w);
+      }
     }
   };
   auto burst = [&]() {
-    bf16x8 a0[MTW], a1[MTW], a2[MTW];
+    bf16x8 al[MTW][WL];
 #pragma unroll
-    for (int j = 0; j < MTW; ++j) {
-      a0[j] = __builtin_bit_cast(bf16x8, A[j][0]); a1[j] = __builtin_bit_cast(bf16x8, A[j][1]); a2[j] = __builtin_bit_cast(bf16x8, A[j][2]);
-    }
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+      for (int l = 0; l < WL; ++l) al[j][l] = __builtin_bit_cast(bf16x8, A[j][l]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bf[e][0]), b1 = __builtin_bit_cast(bf16x8, bf[e][1]), b2 = __builtin_bit_cast(bf16x8, bf[e][2]);
-#define CIDNET_PWX_TERM(AL, BL)                                                                            \
-  _Pragma("unroll") for (int j = 0; j < MTW; ++j)                                                          \
-      acc[j][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[j], BL, acc[j][e], 0, 0, 0)
-      CIDNET_PWX_TERM(a2, b0);                                   // small terms first
-      CIDNET_PWX_TERM(a1, b1);
-      CIDNET_PWX_TERM(a0, b2);
-      CIDNET_PWX_TERM(a1, b0);
-      CIDNET_PWX_TERM(a0, b1);
-      CIDNET_PWX_TERM(a0, b0);
-#undef CIDNET_PWX_TERM
+      bf16x8 bl[XL];
+#pragma unroll
+      for (int l = 0; l < XL; ++l) bl[l] = __builtin_bit_cast(bf16x8, bf[e][l]);
+      // small terms first: level sums 2, 1, 0 (a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0 with three levels each)
+#pragma unroll
+      for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+        for (int i = sum; i >= 0; --i) {
+          if (i >= WL || sum - i >= XL) continue;
+#pragma unroll
+          for (int j = 0; j < MTW; ++j) acc[j][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j][i], bl[sum - i], acc[j][e], 0, 0, 0);
+        }
     }
   };
   // One k-block: split the activations in `raw`, re-request into the same registers (k-block `kn`, if any), MFMA burst,
@@ -318,18 +332,26 @@ inline PwxPlan pwx_plan(int M, int K, long HW) {
   return p;
 }
 
-template <int MTW, int WM>
+template <int MTW, int WM, int WL, int XL>
 void launch_pwx2(const PwxArgs& a, const PwxPlan& p, hipStream_t s) {
   const dim3 grid((unsigned)(a.B * p.tiles_per_sample), (unsigned)p.chunks);
-  if (p.cpg == 6) hipLaunchKernelGGL((pwx_kernel<MTW, WM, 6>), grid, dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL((pwx_kernel<MTW, WM, 8>), grid, dim3(kThreads), 0, s, a);
+  if (p.cpg == 6) hipLaunchKernelGGL((pwx_kernel<MTW, WM, 6, WL, XL>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((pwx_kernel<MTW, WM, 8, WL, XL>), grid, dim3(kThreads), 0, s, a);
+}
+
+template <int MTW, int WL, int XL>
+void launch_pwx1(const PwxArgs& a, const PwxPlan& p, hipStream_t s) {
+  if (p.WM == 1) launch_pwx2<MTW, 1, WL, XL>(a, p, s);
+  else if (p.WM == 2) launch_pwx2<MTW, 2, WL, XL>(a, p, s);
+  else launch_pwx2<MTW, 4, WL, XL>(a, p, s);
 }
 
 template <int MTW>
-void launch_pwx(const PwxArgs& a, const PwxPlan& p, hipStream_t s) {
-  if (p.WM == 1) launch_pwx2<MTW, 1>(a, p, s);
-  else if (p.WM == 2) launch_pwx2<MTW, 2>(a, p, s);
-  else launch_pwx2<MTW, 4>(a, p, s);
+int launch_pwx(const PwxArgs& a, const PwxPlan& p, int wl, int xl, hipStream_t s) {
+  if (wl == 3 && xl == 3) launch_pwx1<MTW, 3, 3>(a, p, s);
+  else if (wl == 1 && xl == 1) launch_pwx1<MTW, 1, 1>(a, p, s);
+  else return CIDNET_ERR_ARG;
+  return CIDNET_OK;
 }
 
 }  // namespace
@@ -381,6 +403,12 @@ int cidnet_pw_conv_bf16x3_prep_batch(const long long* table, int n, long total_b
 /* the product with weights already split by cidnet_pw_conv_bf16x3_prep (Wprep; per_sample: B consecutive sets) */
 int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs, const float* R,
                               long r_bs, int B, int M, int K, long HW, void* stream) {
+  return cidnet_pw_conv_bf16x3_pre_lv(X, x_bs, Wprep, per_sample, Y, y_bs, R, r_bs, B, M, K, HW, 3, 3, stream);
+}
+
+/* w_levels / x_levels: bf16 levels of the weights / activations that enter the products: (3, 3) or (1, 1) */
+int cidnet_pw_conv_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs, const float* R,
+                                 long r_bs, int B, int M, int K, long HW, int w_levels, int x_levels, void* stream) {
   CIDNET_CHECK_ARG(X && Wprep && Y && B > 0);
   if (!cidnet_pw_conv_bf16x3_supported(M, K, HW)) return CIDNET_ERR_SHAPE;
   CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(Wprep) & 15) == 0);
@@ -388,13 +416,15 @@ int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int
   hipStream_t s = (hipStream_t)stream;
   PwxArgs a{X, x_bs, reinterpret_cast<const uint4*>(Wprep), per_sample ? (long)p.KB * p.MT * 3 * 64 : 0L, Y, y_bs, R, r_bs, B, M, K, HW,
             p.KB, p.MT, p.tiles_per_sample};
+  int rc;
   switch (p.MTW) {
-    case 1: launch_pwx<1>(a, p, s); break;
-    case 2: launch_pwx<2>(a, p, s); break;
-    case 3: launch_pwx<3>(a, p, s); break;
-    case 4: launch_pwx<4>(a, p, s); break;
-    default: launch_pwx<5>(a, p, s); break;
+    case 1: rc = launch_pwx<1>(a, p, w_levels, x_levels, s); break;
+    case 2: rc = launch_pwx<2>(a, p, w_levels, x_levels, s); break;
+    case 3: rc = launch_pwx<3>(a, p, w_levels, x_levels, s); break;
+    case 4: rc = launch_pwx<4>(a, p, w_levels, x_levels, s); break;
+    default: rc = launch_pwx<5>(a, p, w_levels, x_levels, s); break;
   }
+  if (rc != CIDNET_OK) return rc;
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -228,6 +228,31 @@ def set_storage_dtype(name):
     STORAGE["hidden"] = torch.bfloat16 if name == "bf16" else torch.float32
 
 
+# ---- bf16 arithmetic mode -------------------------------------------------------------------------------------------------
+# MATH["levels"] = how many bf16 levels of each fp32 operand enter the matrix-core products of the convolutions (1x1, dense
+# 3x3, their weight gradients).  3: the exact three-way split, six products per fp32 product -- results within fp32
+# rounding of an fp32 convolution: the PARITY mode and the default.  1: operands rounded to nearest bf16, one product, fp32
+# accumulation and fp32 output -- the arithmetic of a torch.autocast(bfloat16) convolution (BASELINE.json configs[2]): the
+# activation split in the kernels disappears (11 VALU ops per element pair -> 1) and the matrix-core work drops to a sixth.
+MATH = {"levels": 3}
+
+
+def set_math_levels(n):
+    if n not in (1, 3):
+        raise ValueError("operand levels must be 3 (fp32-exact split products) or 1 (bf16 operands)")
+    MATH["levels"] = int(n)
+
+
+def set_precision(name):
+    """'f32': the parity mode (fp32 storage, fp32-exact products).  'bf16': BASELINE.json configs[2] -- bf16 matrix-core
+    operands (one product per term, fp32 accumulation) and bf16 storage of the tensors listed at STORAGE; its own
+    tolerance tier (tests/test_fullsize_gpu.py)."""
+    if name not in ("f32", "bf16"):
+        raise ValueError("precision must be 'f32' or 'bf16'")
+    set_storage_dtype(name)
+    set_math_levels(1 if name == "bf16" else 3)
+
+
 def _dt(t):
     """element-type code of the C ABI (CIDNET_F32 = 0, CIDNET_BF16 = 1)"""
     return 1 if t.dtype == torch.bfloat16 else 0
@@ -371,20 +396,23 @@ PW_BF16X3 = {"on": os.environ.get("CIDNET_PW_BF16X3", "1") == "1"}
 
 
 def pw_bf16x3_wins(M, K, HW=0):
-    return not (K <= 40 and M >= 150)
+    return MATH["levels"] == 1 or not (K <= 40 and M >= 150)
 
 
 def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
-    n = _raw("cidnet_pw_conv_bf16x3_ws_floats", B, M, K, int(w_bs != 0))
-    if w_bs == 0 and _PREP["on"]:
-        pre = _prepared("pw", w, w_off, w_ms, w_ks, 0, M, K, n, lambda buf: lib().call(
-            "cidnet_pw_conv_bf16x3_prep", _po(w, w_off), 0, w_ms, w_ks, _p(buf), buf.numel(), 1, M, K, _stream()))
-        lib().call("cidnet_pw_conv_bf16x3_pre", _po(x, x_off), x_bs, _p(pre), 0, _po(y, y_off), y_bs,
-                   _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, _stream())
-        return
-    ws = _ws(n, x.device)
-    lib().call("cidnet_pw_conv_bf16x3", _po(x, x_off), x_bs, _po(w, w_off), w_bs, w_ms, w_ks, _po(y, y_off), y_bs,
-               _po(res, r_off) if res is not None else None, r_bs, _p(ws), ws.numel(), B, M, K, HW, _stream())
+    per_sample = int(w_bs != 0)
+    nb = B if per_sample else 1
+    n = _raw("cidnet_pw_conv_bf16x3_ws_floats", B, M, K, per_sample)
+
+    def prepare(buf):
+        lib().call("cidnet_pw_conv_bf16x3_prep", _po(w, w_off), w_bs, w_ms, w_ks, _p(buf), buf.numel(), nb, M, K, _stream())
+    pre = _prepared("pw", w, w_off, w_ms, w_ks, 0, M, K, n, prepare) if not per_sample else None
+    if pre is None:
+        pre = _ws(n, x.device)
+        prepare(pre)
+    lv = MATH["levels"]
+    lib().call("cidnet_pw_conv_bf16x3_pre_lv", _po(x, x_off), x_bs, _p(pre), per_sample, _po(y, y_off), y_bs,
+               _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, lv, lv, _stream())
 
 
 def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
@@ -405,8 +433,9 @@ PW_WGRAD_BF16X3 = {"on": os.environ.get("CIDNET_PW_WGRAD_BF16X3", "1") == "1"}
 def pw_wgrad(dy, dy_off, dy_bs, x, x_off, x_bs, dw, dw_off, dw_ld, B, M, N, HW, per_sample=False):
     n = _raw("cidnet_pw_wgrad_ws_floats", B, M, N, HW)
     ws = _ws(n, dy.device)
+    flags = 4 if MATH["levels"] == 1 else (0 if PW_WGRAD_BF16X3["on"] else 2)      # CIDNET_WGRAD_BF16_1LEVEL / _FP32_MFMA
     lib().call("cidnet_pw_wgrad_t", _pe(dy, dy_off), _dt(dy), dy_bs, _pe(x, x_off), _dt(x), x_bs, _po(dw, dw_off), dw_ld,
-               int(per_sample), 0 if PW_WGRAD_BF16X3["on"] else 2, _p(ws), ws.numel(), B, M, N, HW, _stream())
+               int(per_sample), flags, _p(ws), ws.numel(), B, M, N, HW, _stream())
 
 
 def dw3x3(inp, w1, w2, csplit, out, B, C, H, W, flip=False, addend=None):
@@ -441,15 +470,16 @@ def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, add
     if CONV3_BF16X3["on"] and not replicate and x_bs == K * H * W and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
             and CONV3_BF16X3.get("filter", lambda *a: True)(M, K, H, W):
         n = _raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)
-        if _PREP["on"]:
-            pre = _prepared("c3", w, 0, w_ms, w_ks, int(flip), M, K, n, lambda buf: lib().call(
-                "cidnet_conv3x3_bf16x3_prep", _p(w), w_ms, w_ks, int(flip), _p(buf), buf.numel(), M, K, _stream()))
-            lib().call("cidnet_conv3x3_bf16x3_pre", _p(x), K * H * W, _p(pre), _p(addend), M * H * W, _p(y), M * H * W, B, M, K, H, W,
-                       _stream())
-            return
-        ws = _ws(n, x.device)
-        lib().call("cidnet_conv3x3_bf16x3", _p(x), K * H * W, _p(w), w_ms, w_ks, int(flip), _p(addend), M * H * W, _p(y), M * H * W,
-                   _p(ws), ws.numel(), B, M, K, H, W, _stream())
+
+        def prepare(buf):
+            lib().call("cidnet_conv3x3_bf16x3_prep", _p(w), w_ms, w_ks, int(flip), _p(buf), buf.numel(), M, K, _stream())
+        pre = _prepared("c3", w, 0, w_ms, w_ks, int(flip), M, K, n, prepare)
+        if pre is None:
+            pre = _ws(n, x.device)
+            prepare(pre)
+        lv = MATH["levels"]
+        lib().call("cidnet_conv3x3_bf16x3_pre_lv", _p(x), K * H * W, _p(pre), _p(addend), M * H * W, _p(y), M * H * W, B, M, K, H, W,
+                   lv, lv, _stream())
         return
     if addend is None:
         lib().call("cidnet_conv3x3", _p(x), x_bs, _p(w), w_ms, w_ks, int(flip), int(replicate), _p(y), M * H * W, B, M, K,
@@ -469,8 +499,8 @@ def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False, x_bs=None):
     if CONV3_WGRAD_BF16X3["on"] and not replicate and x_bs == N * H * W and M > 4 and _raw("cidnet_conv3x3_wgrad_bf16x3_supported", M, N, H, W):
         n = _raw("cidnet_conv3x3_wgrad_bf16x3_ws_floats", B, M, N, H, W)
         ws = _ws(n, dy.device)
-        lib().call("cidnet_conv3x3_wgrad_bf16x3", _p(dy), M * H * W, _p(x), N * H * W, _p(dw), _p(ws), ws.numel(), B, M, N, H, W,
-                   _stream())
+        lib().call("cidnet_conv3x3_wgrad_bf16x3_lv", _p(dy), M * H * W, _p(x), N * H * W, _p(dw), _p(ws), ws.numel(), B, M, N, H, W,
+                   MATH["levels"], _stream())
         return
     n = _raw("cidnet_conv3x3_wgrad_ws_floats", B, M, N, H, W)
     ws = _ws(n, dy.device)
@@ -509,7 +539,7 @@ PW_BWD_FUSED = {"on": os.environ.get("CIDNET_PW_BWD_FUSED", "1") == "1", "min_ra
 
 
 def pw_bwd_fused_ok(gy, x, w, M, N, HW):
-    return (PW_BWD_FUSED["on"] and M >= PW_BWD_FUSED["min_ratio"] * N and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32
+    return (PW_BWD_FUSED["on"] and MATH["levels"] == 3 and M >= PW_BWD_FUSED["min_ratio"] * N and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32
             and gy.is_contiguous() and x.is_contiguous() and w.is_contiguous()
             and bool(_raw("cidnet_pw_bwd_fused_supported", M, N, HW)))
 

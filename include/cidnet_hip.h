@@ -134,6 +134,15 @@ int cidnet_pw_conv_bf16x3_prep(const float* Wt, long w_bs, long w_ms, long w_ks,
                                int K, void* stream);
 int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs,
                               const float* R, long r_bs, int B, int M, int K, long HW, void* stream);
+/* w_levels / x_levels: how many bf16 levels of the weights / activations enter the products (all pairs i + j <= 2):
+ * (3, 3) = _pre, the fp32-exact six products; (1, 1) both operands rounded to nearest bf16 and ONE product -- the
+ * arithmetic of a bf16 autocast convolution with fp32 accumulation and fp32 output (BASELINE.json configs[2]'s "bf16"
+ * mode; the activation split disappears and the matrix-core work drops to a sixth).  Other pairs: CIDNET_ERR_ARG (the
+ * 3x3 conv below also takes (3, 1): exact weights, rounded activations, three products).  The prepared operand is the
+ * same for every pair. */
+int cidnet_pw_conv_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs,
+                                 const float* R, long r_bs, int B, int M, int K, long HW, int w_levels, int x_levels,
+                                 void* stream);
 long cidnet_pw_conv_bf16x3_prep_blocks(int M, int K);
 int cidnet_pw_conv_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* Backward of a 1x1 convolution Y = W X (W: (M, N) contiguous) in one kernel: gX (B, N, HW) = W^T gY and dW (M, N) = sum over
@@ -157,6 +166,8 @@ int cidnet_pw_conv_up_prelu(const float* X, long x_bs, const float* Wt, long w_m
  * unless CIDNET_WGRAD_FP32_MFMA is set. */
 #define CIDNET_WGRAD_ACCUMULATE 1
 #define CIDNET_WGRAD_FP32_MFMA 2
+/* both operands rounded to nearest bf16, one product per term (the bf16 mode; any storage types) */
+#define CIDNET_WGRAD_BF16_1LEVEL 4
 long cidnet_pw_wgrad_ws_floats(int B, int M, int N, long HW);
 int cidnet_pw_wgrad_t(const void* dY, int dy_dt, long dy_bs, const void* X, int x_dt, long x_bs, float* dW, long dw_ld,
                       int per_sample, int flags, float* ws, long ws_floats, int B, int M, int N, long HW,
@@ -245,6 +256,8 @@ int cidnet_conv3x3_bf16x3_prep(const float* Wt, long w_ms, long w_ks, int flip, 
                                void* stream);
 int cidnet_conv3x3_bf16x3_pre(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y, long y_bs,
                               int B, int M, int K, int H, int W, void* stream);
+int cidnet_conv3x3_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y,
+                                 long y_bs, int B, int M, int K, int H, int W, int w_levels, int x_levels, void* stream);
 long cidnet_conv3x3_bf16x3_prep_blocks(int M, int K);
 int cidnet_conv3x3_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
@@ -265,6 +278,10 @@ int cidnet_conv3x3_wgrad_bf16x3_supported(int M, int N, int H, int W);
 long cidnet_conv3x3_wgrad_bf16x3_ws_floats(int B, int M, int N, int H, int W);
 int cidnet_conv3x3_wgrad_bf16x3(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws,
                                 long ws_floats, int B, int M, int N, int H, int W, void* stream);
+/* levels: bf16 levels of BOTH operands that enter the products: 3 = the call above (six products, fp32-exact); 1 = operands
+ * rounded to nearest bf16, one product (the bf16 mode, see cidnet_pw_conv_bf16x3_pre_lv) */
+int cidnet_conv3x3_wgrad_bf16x3_lv(const float* dY, long dy_bs, const float* X, long x_bs, float* dW, float* ws,
+                                   long ws_floats, int B, int M, int N, int H, int W, int levels, void* stream);
 #ifdef CIDNET_DEBUG
 /* timing-study switches for cidnet_conv3x3_wgrad_bf16x3 (1 stage only a block's first tile, 2 no fragment reads / MFMAs) */
 void cidnet_debug_c3xw_flags(int flags);

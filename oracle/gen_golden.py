@@ -756,7 +756,70 @@ def gen_round3():
     print("wrote round3.npz", len(out), "arrays")
 
 
+def gen_round4():
+    """Round-4 fixtures, written to tests/golden/round4.npz: BASELINE configs[4] at its image size WITH
+    the backward -- CIDNet_MSSA and CIDNet_TNSM (train mode, loss = L1 + 0.1 mean(fused noise) so that the noise branch
+    trains) forward + backward on 1x3x400x600 through the imported reference: loss, d(loss)/d(input) and a fingerprint
+    (sums + strided sample; small tensors whole) of every live gradient tensor, next to the same from an fp64 evaluation
+    of the oracle (at this size the reference's own fp32 gradients sit 1e-4 .. 1e-2 of a tensor's max from it)."""
+    from net.CIDNet_MSSA import CIDNet as RefMSSA
+    from net.CIDNet_TNSM import CIDNet_TNSM as RefTNSM
+    out = {}
+    shape = (1, 3, 400, 600)
+    x0 = O.synthetic_batch(191, shape)
+    gt = O.synthetic_batch(192, shape)
+    for tag, variant, Ref in (("mssa400", "mssa", RefMSSA), ("tnsm400", "tnsm", RefTNSM)):
+        p = O.make_params(5, variant=variant)
+        m = Ref()
+        load_into(m, p)
+        m.train()
+        x = x0.clone().requires_grad_(True)
+
+        def objective(res, target):
+            if variant == "tnsm":
+                return (res[0] - target).abs().mean() + 0.1 * res[1].mean()
+            return (res - target).abs().mean()
+        res = m(x)
+        loss = objective(res, gt)
+        loss.backward()
+        po = O.params_to(p, requires_grad=True)
+        xo = x0.clone().requires_grad_(True)
+        reso = O.cidnet_tnsm_forward(po, xo) if variant == "tnsm" else O.cidnet_forward(po, xo, variant="mssa")
+        objective(reso, gt).backward()
+        yr = res[0] if variant == "tnsm" else res
+        check_equal(reso[0] if variant == "tnsm" else reso, yr, f"{tag} fwd")
+        live = [(n, prm.grad) for n, prm in m.named_parameters() if prm.grad is not None]
+        dead = [n for n, prm in m.named_parameters() if prm.grad is None]
+        assert all(n.startswith(("I_LCA5.", "I_TNSM5.")) for n in dead), dead
+        worst = max((g - po[n].grad).abs().max().item() / max(g.abs().max().item(), 1e-30) for n, g in live)
+        print(f"  ok  {tag} fwd+bwd through the reference: {len(live)} live gradient tensors, {len(dead)} dead; "
+              f"worst rel-to-max diff oracle vs reference {worst:.2e}")
+        assert worst < 1e-3
+        out[f"{tag}_loss"] = np.float64(loss.item())
+        out[f"{tag}_out_strided"] = yr.detach()[:, :, ::8, ::8].numpy()
+        out[f"{tag}_gx_strided"] = x.grad[:, :, ::8, ::8].numpy()
+        out[f"{tag}_gx_fp"] = O.grad_fingerprint(x.grad)[0].numpy()
+        out[f"{tag}_dead"] = np.array(dead)
+        _store_grads(out, tag, live)
+        del m, res, loss, po, reso
+        p64 = O.params_to(p, dtype=torch.float64, requires_grad=True)
+        x64 = x0.double().requires_grad_(True)
+        r64 = O.cidnet_tnsm_forward(p64, x64) if variant == "tnsm" else O.cidnet_forward(p64, x64, variant="mssa")
+        objective(r64, gt.double()).backward()
+        _store_grads(out, tag + "64", [(n, v.grad.float()) for n, v in p64.items() if v.grad is not None])
+        out[f"{tag}64_gx_strided"] = x64.grad[:, :, ::8, ::8].float().numpy()
+        out[f"{tag}64_gx_fp"] = O.grad_fingerprint(x64.grad)[0].numpy()
+        out[f"{tag}64_out_strided"] = (r64[0] if variant == "tnsm" else r64).detach()[:, :, ::8, ::8].float().numpy()
+        print(f"  {tag}: fp64 evaluation done")
+        del p64, x64, r64
+    np.savez_compressed(os.path.join(GOLD, "round4.npz"), **out)
+    print("wrote round4.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":
+        gen_round4()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round3":
         gen_round3()
         sys.exit(0)
@@ -784,5 +847,6 @@ if __name__ == "__main__":
     gen_lr_schedule()
     gen_fullsize()
     gen_round3()
+    gen_round4()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

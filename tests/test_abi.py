@@ -70,6 +70,7 @@ def test_code_object_checker_sees_a_planted_hazard(tmp_path):
             continue
         found = True
         h = codeobj_check._hazard_checker()
+        assert len(codeobj_check.kernel_symbols(dis, "conv3xw_kernel")) == 2        # operand levels 3 and 1
         assert not h.check(dis, "conv3xw_kernel")[1]
         lines = dis.splitlines()
         last = max(i for i, l in enumerate(lines) if "global_load_dwordx4" in l and "conv3xw" not in l)

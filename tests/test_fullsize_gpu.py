@@ -273,13 +273,13 @@ def test_cidnet_400x600_bf16_storage_mode_vs_reference(golden, dev):
     x1 = O.synthetic_batch(161, (1, 3, 400, 600))
     gt1 = O.synthetic_batch(162, (1, 3, 400, 600))
     x, gt = x1.repeat(8, 1, 1, 1).to(dev), gt1.repeat(8, 1, 1, 1).to(dev)
-    P.set_storage_dtype("bf16")
+    P.set_precision("bf16")
     try:
         y = m(x)
         (y - gt).abs().mean().backward()
         torch.cuda.synchronize()
     finally:
-        P.set_storage_dtype("f32")
+        P.set_precision("f32")
     d = (y[:1, :, ::8, ::8].detach().cpu() - _t(g["a_out_strided"])).abs().max().item()
     print(f"bf16 storage mode, 8x3x400x600: output max |diff| vs the reference {d:.3e}")
     assert d <= 2e-3
@@ -300,3 +300,48 @@ def test_cidnet_400x600_bf16_storage_mode_vs_reference(golden, dev):
         n += 1
     print(f"bf16 storage mode: worst gradient sample error vs fp64 {worst:.3e} of the tensor's max ({wname})")
     assert n == 178
+
+
+@pytest.mark.parametrize("variant,batch", [("mssa", 1), ("mssa", 16), ("tnsm", 1), ("tnsm", 16)])
+def test_variants_400x600_backward_golden(golden, dev, variant, batch):
+    """BASELINE configs[4] with the backward, at its image size and batch: CIDNet_MSSA / CIDNet_TNSM (train mode, loss = L1 +
+    0.1 mean(fused noise) for TNSM) forward + backward on 3x400x600 against tests/golden/round4.npz -- every live gradient
+    tensor of the imported reference (net/CIDNet_MSSA.py:100-159, net/CIDNet_TNSM.py:101-294) as fingerprints, next to an fp64
+    evaluation: ours may be at most twice as far from fp64 as the reference's own fp32 values (check_grad).  batch = 16 uses
+    identical samples: every sample's output equals the single-image fixture and the parameter gradients of the mean loss
+    are unchanged."""
+    import hvi_cidnet_amd as P
+    g = golden("round4")
+    tag = f"{variant}400"
+    m = (P.CIDNet_MSSA if variant == "mssa" else P.CIDNet_TNSM)()
+    load(m, O.make_params(5, variant=variant))
+    m.to(dev).train()
+    x1 = O.synthetic_batch(191, (1, 3, 400, 600))
+    gt1 = O.synthetic_batch(192, (1, 3, 400, 600))
+    x = x1.repeat(batch, 1, 1, 1).to(dev).requires_grad_(True)
+    gt = gt1.repeat(batch, 1, 1, 1).to(dev)
+    res = m(x)
+    y = res[0] if variant == "tnsm" else res
+    loss = (y - gt).abs().mean() + (0.1 * res[1].mean() if variant == "tnsm" else 0.0)
+    ref, r64 = _t(g[f"{tag}_out_strided"]).double(), _t(g[f"{tag}64_out_strided"]).double()
+    ref_err = (ref - r64).abs().max().item()
+    for b in (0, batch - 1):
+        our_err = (y[b:b + 1, :, ::8, ::8].detach().cpu().double() - r64).abs().max().item()
+        assert our_err <= 2.0 * ref_err + 1e-4, f"{tag} sample {b}: output error vs fp64 {our_err:.3e}, the reference's own {ref_err:.3e}"
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) <= 2.0 * ref_err + 1e-5
+    loss.backward()
+    torch.cuda.synchronize()
+    gx = x.grad[batch - 1:batch].detach().cpu() * batch
+    refx, x64 = _t(g[f"{tag}_gx_strided"]).double(), _t(g[f"{tag}64_gx_strided"]).double()
+    ref_err = (refx - x64).abs().max().item()
+    our_err = (gx[:, :, ::8, ::8].double() - x64).abs().max().item()
+    assert our_err <= 2.0 * ref_err + 2e-4 * x64.abs().max().item(), f"{tag} d/dx error vs fp64 {our_err:.3e}, reference's own {ref_err:.3e}"
+    dead = set(str(n) for n in g[f"{tag}_dead"])
+    n = 0
+    for name, prm in m.named_parameters():
+        if name in dead:
+            assert prm.grad is None, name
+            continue
+        check_grad(g, tag, name, prm.grad, tag64=tag + "64")
+        n += 1
+    assert n == (197 if variant == "mssa" else 450)

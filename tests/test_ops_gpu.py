@@ -601,3 +601,103 @@ def test_bilinear_tables_once_per_shape(dev):
         ops.bilinear_bwd(g, b2, B, C, Hi, Wi, Ho, Wo)
         ops.bilinear_bwd(g, b2, B, C, Hi, Wi, Ho, Wo)
         assert torch.equal(a, b2)
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("B,M,K,HW,res", [(2, 36, 95, 60 * 40, True), (1, 190, 36, 75 * 50, False), (2, 72, 191, 1000, True),
+                                          (1, 144, 766, 75 * 50 + 2, False), (2, 288, 144, 129, False)])
+def test_pw_conv_one_level_is_the_bf16_product(dev, B, M, K, HW, res):
+    """ops.set_math_levels(1) (the bf16 mode): the 1x1 conv multiplies operands rounded to nearest bf16, ONE product per term,
+    fp32 accumulation.  Reference = the fp64 product of the rounded operands; what is left is fp32 summation error."""
+    from hvi_cidnet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + K)
+    x = torch.randn(B, K, HW, device=dev, generator=g)
+    w = torch.randn(M, K, device=dev, generator=g) / K ** 0.5
+    r = torch.randn(B, M, HW, device=dev, generator=g) if res else None
+    ref = torch.matmul(_bf16_round(w).cpu(), _bf16_round(x).cpu())
+    if res:
+        ref = ref + r.double().cpu()
+    y = torch.full((B, M, HW), float("nan"), device=dev)
+    ops.set_math_levels(1)
+    try:
+        ops.pw_conv_bf16x3(x, 0, K * HW, w, 0, 0, K, 1, y, 0, M * HW, B, M, K, HW, res=r, r_bs=M * HW)
+    finally:
+        ops.set_math_levels(3)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item() + 1e-6, err
+    # and it is NOT the fp32 product: bf16 rounding of the operands is visible (guards against a silently ignored mode)
+    exact = torch.matmul(w.double().cpu(), x.double().cpu()) + (r.double().cpu() if res else 0)
+    assert (y.double().cpu() - exact).abs().max().item() > 1e-4
+
+
+@pytest.mark.parametrize("B,M,K,H,W,flip,add", [(1, 36, 36, 24, 40, 0, False), (2, 72, 36, 16, 75, 1, True), (1, 36, 72, 20, 34, 0, True)])
+@pytest.mark.parametrize("wl,xl", [(1, 1), (3, 1)])
+def test_conv3x3_level_modes(dev, B, M, K, H, W, flip, add, wl, xl):
+    """cidnet_conv3x3_bf16x3_pre_lv: (1, 1) both operands rounded to bf16, one product; (3, 1) exact weights, rounded
+    activations -- against the fp64 convolution of the correspondingly rounded operands"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    g = torch.Generator(device=dev).manual_seed(M + K + H)
+    x = torch.randn(B, K, H, W, device=dev, generator=g)
+    r = torch.randn(B, M, H, W, device=dev, generator=g) if add else None
+    if flip:
+        wt = torch.randn(K, M, 3, 3, device=dev, generator=g) / (3 * K ** 0.5)
+        w_ms, w_ks = 9, 9 * M
+    else:
+        wt = torch.randn(M, K, 3, 3, device=dev, generator=g) / (3 * K ** 0.5)
+        w_ms, w_ks = 9 * K, 9
+    wr = (_bf16_round(wt) if wl == 1 else wt.double()).cpu()
+    xr = _bf16_round(x).cpu()
+    ref = F.conv_transpose2d(xr, wr, padding=1) if flip else F.conv2d(xr, wr, padding=1)
+    if add:
+        ref = ref + r.double().cpu()
+    n = ops._raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)
+    ws = torch.empty(n, device=dev)
+    y = torch.full((B, M, H, W), float("nan"), device=dev)
+    lib().call("cidnet_conv3x3_bf16x3_prep", ops._p(wt), w_ms, w_ks, flip, ops._p(ws), ws.numel(), M, K, ops._stream())
+    lib().call("cidnet_conv3x3_bf16x3_pre_lv", ops._p(x), K * H * W, ops._p(ws), ops._p(r), M * H * W, ops._p(y), M * H * W, B, M, K, H, W,
+               wl, xl, ops._stream())
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("B,M,N,H,W", [(2, 36, 36, 16, 40), (1, 72, 36, 12, 75), (1, 36, 72, 9, 34)])
+def test_conv3x3_wgrad_one_level(dev, B, M, N, H, W):
+    from hvi_cidnet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + W)
+    x = torch.randn(B, N, H, W, device=dev, generator=g)
+    dy = torch.randn(B, M, H, W, device=dev, generator=g)
+    xr = _bf16_round(x).cpu().requires_grad_(False)
+    wz = torch.zeros(M, N, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wz, padding=1).backward(_bf16_round(dy).cpu())
+    dw = torch.full((M, N, 3, 3), float("nan"), device=dev)
+    ops.set_math_levels(1)
+    try:
+        ops.conv3x3_wgrad(dy, x, dw, B, M, N, H, W)
+    finally:
+        ops.set_math_levels(3)
+    err = (dw.double().cpu() - wz.grad).abs().max().item()
+    assert err <= 1e-5 * wz.grad.abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("B,M,N,HW,dts", [(2, 36, 95, 2400, (0, 0)), (1, 190, 36, 3750, (1, 0)), (2, 72, 72, 1000, (0, 1)), (1, 95, 36, 600, (1, 1))])
+def test_pw_wgrad_one_level(dev, B, M, N, HW, dts):
+    """CIDNET_WGRAD_BF16_1LEVEL with fp32 and bf16-stored operands"""
+    from hvi_cidnet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    dy = torch.randn(B, M, HW, device=dev, generator=g)
+    x = torch.randn(B, N, HW, device=dev, generator=g)
+    ref = torch.einsum("bmp,bnp->mn", _bf16_round(dy).cpu(), _bf16_round(x).cpu())
+    dyt = dy.to(torch.bfloat16) if dts[0] else dy
+    xt = x.to(torch.bfloat16) if dts[1] else x
+    dw = torch.full((M, N), float("nan"), device=dev)
+    ops.set_math_levels(1)
+    try:
+        ops.pw_wgrad(dyt, 0, M * HW, xt, 0, N * HW, dw, 0, N, B, M, N, HW)
+    finally:
+        ops.set_math_levels(3)
+    err = (dw.double().cpu() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item() + 1e-6, err
