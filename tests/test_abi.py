@@ -70,14 +70,24 @@ def test_code_object_checker_sees_a_planted_hazard(tmp_path):
             continue
         found = True
         h = codeobj_check._hazard_checker()
-        assert len(codeobj_check.kernel_symbols(dis, "conv3xw_kernel")) == 2        # operand levels 3 and 1
-        assert not h.check(dis, "conv3xw_kernel")[1]
+        names = codeobj_check.kernel_symbols(dis, "conv3xw_kernel")
+        assert len(names) == 2                                      # operand levels 3 and 1
         lines = dis.splitlines()
-        last = max(i for i, l in enumerate(lines) if "global_load_dwordx4" in l and "conv3xw" not in l)
-        reg = re.search(r"global_load_dwordx4 v\[(\d+):", lines[last]).group(1)
-        bar = next(i for i in range(last, len(lines)) if "s_barrier" in lines[i])
-        lines.insert(bar + 1, f"\tv_mov_b32_e32 v250, v{reg}")
-        assert h.check("\n".join(lines), "conv3xw_kernel")[1]
+        for name in names:
+            assert not h.check(dis, name)[1]
+            start = next(i for i, l in enumerate(lines) if l.rstrip().endswith(f"<{name}>:"))
+            end = next((i for i in range(start + 1, len(lines)) if re.match(r"^[0-9a-f]+ <(?!L\d)", lines[i])), len(lines))
+            # a copy of a load destination right after the barrier that follows the load: at least one load site of the
+            # kernel is still pending there (the loads of the next tile cross the loop edge), and the pass must see it
+            seen = False
+            for site in (i for i in range(start, end) if "global_load_dwordx4" in lines[i]):
+                reg = re.search(r"global_load_dwordx4 v\[(\d+):", lines[site]).group(1)
+                bar = next((i for i in range(site, end) if "s_barrier" in lines[i]), None)
+                if bar is None:
+                    continue
+                planted = lines[:bar + 1] + [f"\tv_mov_b32_e32 v250, v{reg}"] + lines[bar + 1:]
+                seen = seen or bool(h.check("\n".join(planted), name)[1])
+            assert seen, name
     assert found
 
 
