@@ -8,6 +8,7 @@
 //                 [q;k] to [dq;dk] (softmax + normalisation backward folded), applied by pw.hip.
 // q, k, v live in one (B, 3C, HW) tensor: channels [0,C) q, [C,2C) k, [2C,3C) v.
 #include "common.h"
+#include "cidnet_hip.h"
 
 namespace cidnet {
 namespace {
@@ -15,20 +16,22 @@ namespace {
 constexpr int kThreads = 256;
 constexpr float kNormEps = 1e-12f;   // F.normalize eps
 
-__device__ __forceinline__ f32x4 ld_px4(const float* row, long p, long pend, bool ok) {
+// typed row access (DT = CIDNET_F32 / CIDNET_BF16, a compile-time constant): offsets in elements from the tensor's base
+template <int DT>
+__device__ __forceinline__ f32x4 ld_px4(const void* base, long row, long p, long pend, bool ok) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (ok && p < pend) {
-    if (p + 3 < pend) v = load4u(row + p);
+    if (p + 3 < pend) v = ld4t(base, row + p, DT);
     else
       for (int e = 0; e < 4; ++e)
-        if (p + e < pend) v[e] = row[p + e];
+        if (p + e < pend) v[e] = ld1t(base, row + p + e, DT);
   }
   return v;
 }
 
 // slab layout per wave: [ch*ch S][ch nq2][ch nk2]
-template <int TI>
-__global__ __launch_bounds__(kThreads) void gram_kernel(const float* __restrict__ qkv, float* __restrict__ slabs, int C,
+template <int TI, int DT = 0>           // DT: storage type of qkv (bf16 in the bf16 mode; the products stay fp32)
+__global__ __launch_bounds__(kThreads) void gram_kernel(const void* __restrict__ qkv, float* __restrict__ slabs, int C,
                                                         int heads, long HW, int pch) {
   const int ch = C / heads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -36,8 +39,8 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const float* __restrict_
   const int head = blockIdx.y, b = blockIdx.z;
   const long pbeg = (long)blockIdx.x * pch;
   const long pend = (pbeg + pch < HW) ? pbeg + pch : HW;
-  const float* qb = qkv + ((long)b * 3 * C + (long)head * ch) * HW;
-  const float* kb = qb + (long)C * HW;
+  const long qb = ((long)b * 3 * C + (long)head * ch) * HW;    // element offsets into qkv
+  const long kb = qb + (long)C * HW;
 
   f32x4 acc[TI][TI];
   float nq[TI], nk[TI];
@@ -51,8 +54,7 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const float* __restrict_
   // never stored), and the step that crosses the end of the chunk is pulled back to pend-8 with its first `dup`
   // pixels (owned by the previous k-slot) masked out of q.  The next step's loads are issued before this step's
   // MFMAs and consumed one iteration later, so their latency hides behind the burst.
-  const float* qrow[TI];
-  const float* krow[TI];
+  long qrow[TI], krow[TI];
 #pragma unroll
   for (int t = 0; t < TI; ++t) {
     const long row = min(t * 16 + r, ch - 1);
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const float* __restrict_
     const long pl = min(p + 8 * j, pend - 8);
 #pragma unroll
     for (int t = 0; t < TI; ++t) {
-      qn[t][0] = load4u(qrow[t] + pl); qn[t][1] = load4u(qrow[t] + pl + 4);
-      kn[t][0] = load4u(krow[t] + pl); kn[t][1] = load4u(krow[t] + pl + 4);
+      qn[t][0] = ld4t(qkv, qrow[t] + pl, DT); qn[t][1] = ld4t(qkv, qrow[t] + pl + 4, DT);
+      kn[t][0] = ld4t(qkv, krow[t] + pl, DT); kn[t][1] = ld4t(qkv, krow[t] + pl + 4, DT);
     }
   };
   long p = pbeg + wave * 32;
@@ -93,8 +95,8 @@ __global__ __launch_bounds__(kThreads) void gram_kernel(const float* __restrict_
 #pragma unroll
       for (int t = 0; t < TI; ++t) {
         const bool ok = t * 16 + r < ch;
-        qa[t][0] = ld_px4(qrow[t], pl, pend, ok); qa[t][1] = ld_px4(qrow[t], pl + 4, pend, ok);
-        ka[t][0] = ld_px4(krow[t], pl, pend, ok); ka[t][1] = ld_px4(krow[t], pl + 4, pend, ok);
+        qa[t][0] = ld_px4<DT>(qkv, qrow[t], pl, pend, ok); qa[t][1] = ld_px4<DT>(qkv, qrow[t], pl + 4, pend, ok);
+        ka[t][0] = ld_px4<DT>(qkv, krow[t], pl, pend, ok); ka[t][1] = ld_px4<DT>(qkv, krow[t], pl + 4, pend, ok);
       }
     }
 #pragma unroll
@@ -325,7 +327,13 @@ long cidnet_attn_gram_ws_floats(int B, int C, int heads, long HW) {
 /* fwd: gram + softmax + fold with project_out.  Outputs attn/shat (B,heads,ch,ch), nq/nk (B,C), M (B,C,C). */
 int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp, float* attn, float* shat, float* nq,
                     float* nk, float* M, float* ws, long ws_floats, int B, int C, int heads, long HW, int normalize, void* stream) {
-  CIDNET_CHECK_ARG(qkv && temperature && Wp && attn && shat && nq && nk && M && ws && B > 0 && C > 0 && heads > 0 && HW > 0);
+  return cidnet_attn_fwd_t(qkv, CIDNET_F32, temperature, Wp, attn, shat, nq, nk, M, ws, ws_floats, B, C, heads, HW, normalize, stream);
+}
+
+/* qkv stored as fp32 or bf16 (qkv_dt); everything else as cidnet_attn_fwd */
+int cidnet_attn_fwd_t(const void* qkv, int qkv_dt, const float* temperature, const float* Wp, float* attn, float* shat, float* nq,
+                      float* nk, float* M, float* ws, long ws_floats, int B, int C, int heads, long HW, int normalize, void* stream) {
+  CIDNET_CHECK_ARG(qkv && temperature && Wp && attn && shat && nq && nk && M && ws && B > 0 && C > 0 && heads > 0 && HW > 0 && (qkv_dt | 1) == 1);
   if (C % heads != 0 || C / heads > 32) return CIDNET_ERR_SHAPE;
   if (ws_floats < cidnet_attn_gram_ws_floats(B, C, heads, HW)) return CIDNET_ERR_WS;
   const int ch = C / heads;
@@ -333,8 +341,13 @@ int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp,
   const int chunks = (int)((HW + pch - 1) / pch);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)chunks, (unsigned)heads, (unsigned)B);
-  if (ch <= 16) hipLaunchKernelGGL((gram_kernel<1>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
-  else hipLaunchKernelGGL((gram_kernel<2>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
+  if (qkv_dt) {
+    if (ch <= 16) hipLaunchKernelGGL((gram_kernel<1, 1>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
+    else hipLaunchKernelGGL((gram_kernel<2, 1>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
+  } else {
+    if (ch <= 16) hipLaunchKernelGGL((gram_kernel<1, 0>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
+    else hipLaunchKernelGGL((gram_kernel<2, 0>), grid, dim3(kThreads), 0, s, qkv, ws, C, heads, HW, pch);
+  }
   CIDNET_LAUNCH_STATUS();
   const size_t lds = (size_t)(2 * ch * ch + 2 * ch + C * ch) * sizeof(float);
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)heads, (unsigned)B), dim3(kThreads), lds, s, ws, chunks * 4,

@@ -217,8 +217,12 @@ __device__ __attribute__((noinline)) void store_ragged(float* yp, const float* r
 // bf16, one product -- the arithmetic of a bf16 autocast conv with fp32 accumulation and fp32 output; the staging pass then
 // converts instead of splitting (1 VALU op per pair instead of 11) and the tile takes a third of the LDS.  (3, 1): exact
 // weights, rounded activations, three products.
+// resident blocks per CU: 2 with three activation levels (73 KB of LDS, ~180 VGPRs); 4 with one (24 KB, ~116 VGPRs) -- that
+// mode has a sixth of the matrix-core work and lives on loads in flight
+constexpr int x3_blocks_per_cu(int xl) { return xl == 1 ? 4 : 2; }
+
 template <int KCH, int WL, int XL>
-__global__ __launch_bounds__(kXThreads, 2) void conv3x_kernel(X3Args a) {
+__global__ __launch_bounds__(kXThreads, x3_blocks_per_cu(XL)) void conv3x_kernel(X3Args a) {
   using T = X3<KCH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char xs[];       // [XL][PH][RP] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,7 +430,7 @@ int launch_conv3x(X3Args a, const float* wprep, hipStream_t s) {
   static LdsLimit lds;                                        // once per device: the kernel's dynamic-LDS limit
   if (const hipError_t e = lds.raise(reinterpret_cast<const void*>(&conv3x_kernel<KCH, WL, XL>), lds_bytes); e != hipSuccess) return (int)e;
   const long nwork = (long)a.B * a.tiles_x * a.tiles_y * a.mchunks;
-  long nblk = 512;                                            // persistent: two resident blocks per CU
+  long nblk = 256 * x3_blocks_per_cu(XL);                     // persistent: every resident slot of the 256 CUs
   if (nblk > nwork) nblk = nwork;
   a.stagger = 2;                                              // ~8k cycles: about the length of a staging phase
   hipLaunchKernelGGL((conv3x_kernel<KCH, WL, XL>), dim3((unsigned)nblk), dim3(kXThreads), lds_bytes, s, a);

@@ -10,6 +10,7 @@
 // plane count allows, because every strip re-reads its halo rows.  HBM-bound by construction.
 #include <type_traits>
 #include "common.h"
+#include "cidnet_hip.h"
 #include "stencil.h"
 
 namespace cidnet {
@@ -108,19 +109,19 @@ __device__ __forceinline__ void load_w9(const float* w1, const float* w2, int cs
 }
 
 // out = dwconv3x3(in) [+ addend]
-template <bool NARROW>
-__global__ __launch_bounds__(kThreads) void dw3x3_kernel(const float* __restrict__ in, const float* __restrict__ w1,
+template <bool NARROW, class T = float>     // T: storage type of in / addend / out (float, or bf16_t in the bf16 mode)
+__global__ __launch_bounds__(kThreads) void dw3x3_kernel(const T* __restrict__ in, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, int csplit,
-                                                         const float* __restrict__ addend, float* __restrict__ out, int flip,
+                                                         const T* __restrict__ addend, T* __restrict__ out, int flip,
                                                          int B, int C, int H, int W, Tiling tl) {
   const Item it = decode_item<NARROW>((long)B * C, tl, W);
   if (!it.live) return;
   float w[9];
   load_w9(w1, w2, csplit, (int)(it.bc % C), flip != 0, w);
   const long HW = (long)H * W;
-  const float* ip = in + it.bc * HW;
-  float* op = out + it.bc * HW;
-  const float* ap = addend ? addend + it.bc * HW : nullptr;
+  const T* ip = in + it.bc * HW;
+  T* op = out + it.bc * HW;
+  const T* ap = addend ? addend + it.bc * HW : nullptr;
   Win6 r0 = load_win6<false, NARROW>(ip, it.y0 - 1, it.x0, H, W);
   Win6 r1 = load_win6<false, NARROW>(ip, it.y0, it.x0, H, W);
   const int yend = min(it.y0 + tl.rows, H);
@@ -592,12 +593,23 @@ void cidnet_debug_dw_rows(int rows) { g_dw_force_rows = rows; }
 
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend, float* out, int flip,
                  int B, int C, int H, int W, void* stream) {
-  CIDNET_CHECK_ARG(in && w1 && out && B > 0 && C > 0 && H > 0 && W > 0);
+  return cidnet_dw3x3_t(in, w1, w2, csplit, addend, out, CIDNET_F32, flip, B, C, H, W, stream);
+}
+
+/* in / addend / out stored as fp32 or bf16 (one type, dt) */
+int cidnet_dw3x3_t(const void* in, const float* w1, const float* w2, int csplit, const void* addend, void* out, int dt, int flip,
+                   int B, int C, int H, int W, void* stream) {
+  CIDNET_CHECK_ARG(in && w1 && out && B > 0 && C > 0 && H > 0 && W > 0 && (dt | 1) == 1);
   CIDNET_CHECK_ARG(csplit >= C || w2);
   const Tiling tl = fwd_tiling((long)B * C, H, W);
   const long items = n_items((long)B * C, tl);
-  CIDNET_LAUNCH_NW(W, (dw3x3_kernel<true>), (dw3x3_kernel<false>), dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     (hipStream_t)stream, in, w1, w2, csplit, addend, out, flip, B, C, H, W, tl);
+  const dim3 grid((unsigned)((items + kThreads - 1) / kThreads));
+  if (dt)
+    CIDNET_LAUNCH_NW(W, (dw3x3_kernel<true, bf16_t>), (dw3x3_kernel<false, bf16_t>), grid, dim3(kThreads), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, w1, w2, csplit, (const bf16_t*)addend, (bf16_t*)out, flip, B, C, H, W, tl);
+  else
+    CIDNET_LAUNCH_NW(W, (dw3x3_kernel<true, float>), (dw3x3_kernel<false, float>), grid, dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float*)in, w1, w2, csplit, (const float*)addend, (float*)out, flip, B, C, H, W, tl);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -10,6 +10,7 @@
 // sum => bitwise reproducible, no atomics).
 #include <cstdlib>
 #include "common.h"
+#include "cidnet_hip.h"
 
 namespace cidnet {
 namespace {
@@ -22,6 +23,8 @@ template <> struct Vec<4> {
   typedef f32x4 T;
   static __device__ __forceinline__ T ld(const float* p) { return load4u(p); }
   static __device__ __forceinline__ void st(float* p, T v) { store4u(p, v); }
+  static __device__ __forceinline__ T ld(const bf16_t* p) { return ld4t(p, 0, 1); }        // bf16-stored tensors (bf16 mode)
+  static __device__ __forceinline__ void st(bf16_t* p, T v) { st4t(p, 0, 1, v); }
   static __device__ __forceinline__ float hsum(T v) { return (v[0] + v[1]) + (v[2] + v[3]); }
   template <int LPP> static __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
@@ -37,6 +40,8 @@ template <> struct Vec<2> {
   typedef f32x2 T;
   static __device__ __forceinline__ T ld(const float* p) { f2u v = *reinterpret_cast<const f2u*>(p); T r = {v.x, v.y}; return r; }
   static __device__ __forceinline__ void st(float* p, T v) { f2u s; s.x = v[0]; s.y = v[1]; *reinterpret_cast<f2u*>(p) = s; }
+  static __device__ __forceinline__ T ld(const bf16_t* p) { const h2u v = *reinterpret_cast<const h2u*>(p); T r = {bf16_to_f32(v.x), bf16_to_f32(v.y)}; return r; }
+  static __device__ __forceinline__ void st(bf16_t* p, T v) { h2u s; s.x = f32_to_bf16(v[0]); s.y = f32_to_bf16(v[1]); *reinterpret_cast<h2u*>(p) = s; }
   static __device__ __forceinline__ float hsum(T v) { return v[0] + v[1]; }
   template <int LPP> static __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
@@ -51,6 +56,8 @@ template <> struct Vec<1> {
   typedef float T;
   static __device__ __forceinline__ T ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ T ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, T v) { *p = f32_to_bf16(v); }
   static __device__ __forceinline__ float hsum(T v) { return v; }
   template <int LPP> static __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
@@ -74,11 +81,11 @@ template <> __device__ __forceinline__ f32x4 vrsqrt_eps<4>(f32x4 v, float invC, 
 // ---- register-resident column kernels (HW % VEC == 0) -----------------------------------------
 // w2 / bias2 / y2 (all or none): a second LayerNorm MODULE applied to the same tensor (the x-norm of one LCA block and the
 // y-norm of its partner, net/LCA.py:79,91): the normalised value is the same, so the tensor is read once and written twice
-template <int C, int VEC>
+template <int C, int VEC, class TY = float>                 // TY: storage type of the outputs y / y2 (bf16_t in the bf16 mode)
 __global__ __launch_bounds__(kThreads) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              const float* __restrict__ bias, TY* __restrict__ y,
                                                               const float* __restrict__ w2, const float* __restrict__ bias2,
-                                                              float* __restrict__ y2,
+                                                              TY* __restrict__ y2,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int B,
                                                               long HW, float eps) {
   typedef typename Vec<VEC>::T V;
@@ -99,11 +106,11 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_reg_kernel(const float* __res
 #pragma unroll
     for (int c = 1; c < C; ++c) { const V d = col[c] - u; v += d * d; }
     const V rs = vrsqrt_eps<VEC>(v, invC, eps);
-    float* yb = y + b * C * HW + p;
+    TY* yb = y + b * C * HW + p;
 #pragma unroll
     for (int c = 0; c < C; ++c) Vec<VEC>::st(yb + (long)c * HW, (col[c] - u) * rs * w[c] + bias[c]);
     if (y2) {
-      float* y2b = y2 + b * C * HW + p;
+      TY* y2b = y2 + b * C * HW + p;
 #pragma unroll
       for (int c = 0; c < C; ++c) Vec<VEC>::st(y2b + (long)c * HW, (col[c] - u) * rs * w2[c] + bias2[c]);
     }
@@ -204,10 +211,11 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_kernel(const float* __re
 // DUAL: two LayerNorm modules were applied to the same x (ln_fwd_reg_kernel's second output): the input gradient is linear
 // in g = gy*w, so gx = LN'(gy*w + gy2*w2) in one pass over x; the second module's dw / db partials follow the first's in
 // `part` (4 C floats per block).
-template <int CQ, int VEC, int LPP, bool DUAL = false>      // LPP lanes per pixel vector (4 or 8), CQ = C / LPP channels per lane
+// TG: storage type of the incoming gradients gy / gy2 (bf16_t in the bf16 mode: they are outputs of 1x1 convs there)
+template <int CQ, int VEC, int LPP, bool DUAL = false, class TG = float>      // LPP lanes per pixel vector (4 or 8), CQ = C / LPP channels per lane
 __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                     const float* __restrict__ gy, const float* __restrict__ w2,
-                                                                     const float* __restrict__ gy2, const float* __restrict__ mean,
+                                                                     const TG* __restrict__ gy, const float* __restrict__ w2,
+                                                                     const TG* __restrict__ gy2, const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, const float* __restrict__ addend,
                                                                      float* __restrict__ gx, float* __restrict__ part, int B, long HW) {
   typedef typename Vec<VEC>::T V;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_quad_fused_kernel(const float
     const long b = it / nq, p = (it - b * nq) * VEC;
     const long base = (b * C + (long)q * CQ) * HW + p;
     const float* xb = x + base;
-    const float* gb = gy + base;
+    const TG* gb = gy + base;
     const V u = Vec<VEC>::ld(mean + b * HW + p), rs = Vec<VEC>::ld(rstd + b * HW + p);
     V xh[CQ], gw[CQ];
 #pragma unroll
@@ -440,22 +448,45 @@ extern "C" {
 
 int cidnet_ln_cf_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd, int B,
                      int C, long HW, float eps, void* stream) {
-  CIDNET_CHECK_ARG(x && weight && bias && y && B > 0 && C > 0 && HW > 0);
+  return cidnet_ln_cf_fwd_t(x, weight, bias, y, CIDNET_F32, mean, rstd, B, C, HW, eps, stream);
+}
+
+/* shapes whose LayerNorm output / incoming gradient may be STORED as bf16 (y_dt / gy_dt = CIDNET_BF16): the register-resident
+ * forward and the fused backward kernels -- CIDNet's 36 / 72 / 144-channel levels */
+int cidnet_ln_cf_typed_supported(int B, int C, long HW) {
+  return B > 0 && HW > 0 && ((C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0) || (C == 144 && (long)B * HW <= (1L << 18))) ? 1 : 0;
+}
+
+int cidnet_ln_cf_fwd_t(const float* x, const float* weight, const float* bias, void* y, int y_dt, float* mean, float* rstd, int B,
+                       int C, long HW, float eps, void* stream) {
+  CIDNET_CHECK_ARG(x && weight && bias && y && B > 0 && C > 0 && HW > 0 && (y_dt | 1) == 1);
   CIDNET_CHECK_ARG((mean == nullptr) == (rstd == nullptr));
   hipStream_t s = (hipStream_t)stream;
+  if (y_dt) {
+    if (!cidnet_ln_cf_typed_supported(B, C, HW)) return CIDNET_ERR_SHAPE;
+    bf16_t* yh = reinterpret_cast<bf16_t*>(y);
+#define CIDNET_LN_FWD_H(CC)                                                                                                        \
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<CC, 1, bf16_t>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, yh, \
+                       (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, mean, rstd, B, HW, eps)
+    if (C == 36) CIDNET_LN_FWD_H(36); else if (C == 72) CIDNET_LN_FWD_H(72); else CIDNET_LN_FWD_H(144);
+#undef CIDNET_LN_FWD_H
+    CIDNET_LAUNCH_STATUS();
+    return CIDNET_OK;
+  }
+  float* yf = reinterpret_cast<float*>(y);
   // C = 36: one pixel per lane (36 registers of column) -- 4 pixels per lane left under two waves per SIMD for the whole
   // launch at 200x300, i.e. one read burst followed by one write burst: 26.8 -> 23.7 us (tools/micro_ln.py)
   if (C == 36)
-    hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<36, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, yf,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, mean, rstd, B, HW, eps);
   else if (C == 72)                                           // one pixel per lane, as for C = 36: 21 -> 17 us at 100x150
-    hipLaunchKernelGGL((ln_fwd_reg_kernel<72, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<72, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, yf,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, mean, rstd, B, HW, eps);
   else if (C == 144)
-    hipLaunchKernelGGL((ln_fwd_reg_kernel<144, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, y,
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<144, 1>), dim3(grid_for((long)B * HW)), dim3(kThreads), 0, s, x, weight, bias, yf,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, mean, rstd, B, HW, eps);
   else
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, s, x, weight, bias, y, mean,
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, s, x, weight, bias, yf, mean,
                        rstd, B, C, HW, eps);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
@@ -472,12 +503,35 @@ long cidnet_ln_cf_bwd_ws_floats(int C) {
 int cidnet_ln_cf_bwd_res(const float* x, const float* weight, const float* gy, const float* mean, const float* rstd,
                          const float* addend, float* gx, float* gw, float* gb, int accumulate, float* ws, long ws_floats, int B,
                          int C, long HW, void* stream) {
-  CIDNET_CHECK_ARG(x && weight && gy && mean && rstd && gw && gb && ws && B > 0 && C > 0 && HW > 0);
+  return cidnet_ln_cf_bwd_res_t(x, weight, gy, CIDNET_F32, mean, rstd, addend, gx, gw, gb, accumulate, ws, ws_floats, B, C, HW, stream);
+}
+
+/* gy stored as fp32 or bf16 (gy_dt; bf16: cidnet_ln_cf_typed_supported shapes, gx required) */
+int cidnet_ln_cf_bwd_res_t(const float* x, const float* weight, const void* gy_, int gy_dt, const float* mean, const float* rstd,
+                           const float* addend, float* gx, float* gw, float* gb, int accumulate, float* ws, long ws_floats, int B,
+                           int C, long HW, void* stream) {
+  CIDNET_CHECK_ARG(x && weight && gy_ && mean && rstd && gw && gb && ws && B > 0 && C > 0 && HW > 0 && (gy_dt | 1) == 1);
   const int nchunk = wb_chunks(B, C, HW);
   if (ws_floats < 2L * C * nchunk) return CIDNET_ERR_WS;
   static const bool env_read = (g_ln_unfused = std::getenv("CIDNET_LN_UNFUSED") != nullptr, true);
   (void)env_read;
   hipStream_t s = (hipStream_t)stream;
+  if (gy_dt) {
+    if (!gx || !cidnet_ln_cf_typed_supported(B, C, HW) || ws_floats < 2L * C * kFusedBlocks) return CIDNET_ERR_SHAPE;
+    const bf16_t* gh = reinterpret_cast<const bf16_t*>(gy_);
+    const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 4 : (HW % 2 == 0 ? (long)B * HW * 4 : (long)B * HW * 8));
+    const int nblk = (int)((lanes + kThreads - 1) / kThreads < kFusedBlocks ? (lanes + kThreads - 1) / kThreads : kFusedBlocks);
+#define CIDNET_LN_BWD_H(CQ, VEC, LPP)                                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_quad_fused_kernel<CQ, VEC, LPP, false, bf16_t>), dim3(nblk), dim3(kThreads), 0, s, x, weight, gh,         \
+                       (const float*)nullptr, (const bf16_t*)nullptr, mean, rstd, addend, gx, ws, B, HW)
+    if (C == 36) CIDNET_LN_BWD_H(9, 4, 4); else if (C == 72) CIDNET_LN_BWD_H(9, 2, 8); else if (HW % 2 == 0) CIDNET_LN_BWD_H(18, 2, 8); else CIDNET_LN_BWD_H(18, 1, 8);
+#undef CIDNET_LN_BWD_H
+    CIDNET_LAUNCH_STATUS();
+    hipLaunchKernelGGL(ln_wb2_reduce_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, s, ws, nblk, C, gw, gb, accumulate, 2 * C, 0);
+    CIDNET_LAUNCH_STATUS();
+    return CIDNET_OK;
+  }
+  const float* gy = reinterpret_cast<const float*>(gy_);
   if (gx && ((C == 36 && HW % 4 == 0) || (C == 72 && HW % 2 == 0) || (C == 144 && (long)B * HW <= (1L << 18))) &&
       ws_floats >= 2L * C * kFusedBlocks && !g_ln_unfused) {
     const long lanes = C == 36 ? (long)B * HW : (C == 72 ? (long)B * HW * 4 : (HW % 2 == 0 ? (long)B * HW * 4 : (long)B * HW * 8));

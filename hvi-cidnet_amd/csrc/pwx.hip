@@ -31,10 +31,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kThreads = 256;
 
 struct PwxArgs {
-  const float* X; long x_bs;
+  const void* X; long x_bs;            // fp32, or bf16 (template parameter XB) in the bf16 mode; strides in elements
   const uint4* Af; long a_bs;          // split weights in fragment order; a_bs = fragments-per-sample * 64 (0: shared)
-  float* Y; long y_bs;
-  const float* R; long r_bs;
+  void* Y; long y_bs;                  // fp32 or bf16 (YB)
+  const float* R; long r_bs;           // the residual stream stays fp32
   int B, M, K; long HW;
   int KB, MT;                          // k-blocks of 32, 16-row tiles of M
   int tiles_per_sample;                // block pixel tiles (4 / WM * 64 pixels) per sample
@@ -122,8 +122,13 @@ __global__ __launch_bounds__(kThreads) void pwx_split_w_batch_kernel(const long 
 // (3, 3) the fp32-exact six products (parity mode); (1, 1) both operands rounded to nearest bf16, one product (the
 // arithmetic of a bf16 autocast conv, fp32 accumulation and output), the activations converted instead of split;
 // (3, 1) exact weights, rounded activations.
-template <int MTW, int WM, int CPG, int WL, int XL>
+// XB / YB: the activations / the output are STORED as bf16 (bf16 mode only: XB needs XL == 1 -- a bf16 value has one level).
+// A lane then loads 8 bytes per channel (four pixels) and packs the channel pairs of a pixel with one v_perm each; the
+// output is rounded to nearest bf16 on store (8 bytes per row and lane).
+template <int MTW, int WM, int CPG, int WL, int XL, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
+  static_assert(!XB || XL == 1, "bf16 activations have one level");
+  using Raw = std::conditional_t<XB, uint2, f32x4>;              // four pixels of one channel as loaded
   constexpr int NG = 4 / WM;                                     // pixel groups per block
   constexpr int NP = CPG / 2;                                    // channel pairs = non-zero dwords of a B fragment
   constexpr bool DEEP = MTW <= PWX_DEEP_MAX_MTW;
@@ -141,7 +146,8 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
   const long p0 = p0o + 64 <= HW ? p0o : HW - 64;
   const long pq = p0 + 4 * n;                                    // this lane's pixel quad
   const int K = a.K;
-  const float* Xb = a.X + (long)b * a.x_bs;
+  const float* Xb = reinterpret_cast<const float*>(a.X) + (XB ? 0 : (long)b * a.x_bs);
+  const bf16_t* Xh = reinterpret_cast<const bf16_t*>(a.X) + (XB ? (long)b * a.x_bs : 0);
   const uint4* Au = a.Af + (long)b * a.a_bs;                     // wave-uniform base; lanes differ by `lane` only
   const bool stores = pq + 3 >= p0o;                             // else: quad owned by the previous group
   const bool whole = pq >= p0o;                                  // else: a quad that straddles p0o (HW % 4 != 0 only)
@@ -181,11 +187,16 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
       for (int l = 0; l < WL; ++l) A[j][l] = Am[l * 64 + lane];
     }
   };
-  auto load_raw = [&](f32x4 (&raw)[CPG], int kb) {
+  auto load_raw = [&](Raw (&raw)[CPG], int kb) {
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
       const unsigned k = (unsigned)min(kb * (4 * CPG) + g * CPG + c, K - 1);   // rows past K: finite data times a zero weight
-      raw[c] = load4u(Xb + (k * uHW + upq));
+      if constexpr (XB) {
+        const h4u v = *reinterpret_cast<const h4u*>(Xh + (k * uHW + upq));
+        raw[c] = uint2{(unsigned)v.x | ((unsigned)v.y << 16), (unsigned)v.z | ((unsigned)v.w << 16)};
+      } else {
+        raw[c] = load4u(Xb + (k * uHW + upq));
+      }
     }
   };
   // B fragments of the four N-tiles, three levels each: dword q of a fragment = channel pair q of the lane group
@@ -195,10 +206,20 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
 #pragma unroll
     for (int l = 0; l < XL; ++l) bf[e][l] = uint4{0u, 0u, 0u, 0u};
   auto cvt_pair = [](float p, float q) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{p, q}, bf16x2)); };
-  auto split_raw = [&](f32x4 (&raw)[CPG]) {
+  auto split_raw = [&](Raw (&raw)[CPG]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if constexpr (XL == 1) {
+      if constexpr (XB) {
+        // pixel e of channels (c, c + 1): halves e & 1 of dword e >> 1 of the two channels' quads, one v_perm_b32
+        auto pk = [&](const uint2& lo, const uint2& hi) {
+          const unsigned l = e < 2 ? lo.x : lo.y, h = e < 2 ? hi.x : hi.y;
+          return __builtin_amdgcn_perm(h, l, (e & 1) ? 0x07060302u : 0x05040100u);
+        };
+        bf[e][0].x = pk(raw[0], raw[1]);
+        bf[e][0].y = pk(raw[2], raw[3]);
+        if constexpr (NP > 2) bf[e][0].z = pk(raw[4], raw[5]);
+        if constexpr (NP > 3) bf[e][0].w = pk(raw[6], raw[7]);
+      } else if constexpr (XL == 1) {
         bf[e][0].x = cvt_pair(raw[0][e], raw[1][e]);
         bf[e][0].y = cvt_pair(raw[2][e], raw[3][e]);
         if constexpr (NP > 2) bf[e][0].z = cvt_pair(raw[4][e], raw[5][e]);
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
   // are dead (split) before new loads are requested into them and the weight registers are re-requested only after the
   // burst has read them -- without them the scheduler hoists both requests and the five-tile wave spills.  LOAD / LAST are
   // compile-time so that every path is straight-line code with exact counted waits.
-  auto step = [&](f32x4 (&raw)[CPG], int kb, int kn, auto load_tag, auto last_tag) {
+  auto step = [&](Raw (&raw)[CPG], int kb, int kn, auto load_tag, auto last_tag) {
     split_raw(raw);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (decltype(load_tag)::value) load_raw(raw, kn);
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
   if constexpr (DEEP) {
     // two k-blocks of activations in flight (16 KB per wave): X(kb+2) is requested when X(kb) has been split; the burst
     // waits for W(kb), which is younger than X(kb+1) only -- requested a whole step earlier
-    f32x4 r0[CPG], r1[CPG];
+    Raw r0[CPG], r1[CPG];
     load_raw(r0, 0);
     if (KB > 1) load_raw(r1, 1);
     load_a(0);
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
       step(r0, kb, 0, no, yes);
     }
   } else {
-    f32x4 r0[CPG];
+    Raw r0[CPG];
     load_raw(r0, 0);
     load_a(0);
     int kb = 0;
@@ -294,18 +315,28 @@ __global__ __launch_bounds__(kThreads, 2) void pwx_kernel(PwxArgs a) {
       if (m >= a.M) continue;
       const long o = (long)m * HW + pq;
       float v0 = acc[j][0][r], v1 = acc[j][1][r], v2 = acc[j][2][r], v3 = acc[j][3][r];
-      float* yp = a.Y + (long)b * a.y_bs + o;
+      const long yo = (long)b * a.y_bs + o;
       const float* rp = (!PWX_RINIT && a.R) ? a.R + (long)b * a.r_bs + o : nullptr;
       if (whole) {
         if (rp) {
           const f32x4 r4 = load4u(rp);
           v0 += r4[0]; v1 += r4[1]; v2 += r4[2]; v3 += r4[3];
         }
-        store4u(yp, f32x4{v0, v1, v2, v3});
+        if constexpr (YB) {
+          h4u hq;
+          hq.x = f32_to_bf16(v0); hq.y = f32_to_bf16(v1); hq.z = f32_to_bf16(v2); hq.w = f32_to_bf16(v3);
+          *reinterpret_cast<h4u*>(reinterpret_cast<bf16_t*>(a.Y) + yo) = hq;
+        } else {
+          store4u(reinterpret_cast<float*>(a.Y) + yo, f32x4{v0, v1, v2, v3});
+        }
       } else {
         const float vv[4] = {v0, v1, v2, v3};
         for (int e = 0; e < 4; ++e)
-          if (pq + e >= p0o) yp[e] = vv[e] + (rp ? rp[e] : 0.f);
+          if (pq + e >= p0o) {
+            const float t = vv[e] + (rp ? rp[e] : 0.f);
+            if constexpr (YB) reinterpret_cast<bf16_t*>(a.Y)[yo + e] = f32_to_bf16(t);
+            else reinterpret_cast<float*>(a.Y)[yo + e] = t;
+          }
       }
     }
   }
@@ -332,24 +363,28 @@ inline PwxPlan pwx_plan(int M, int K, long HW) {
   return p;
 }
 
-template <int MTW, int WM, int WL, int XL>
+template <int MTW, int WM, int WL, int XL, bool XB, bool YB>
 void launch_pwx2(const PwxArgs& a, const PwxPlan& p, hipStream_t s) {
   const dim3 grid((unsigned)(a.B * p.tiles_per_sample), (unsigned)p.chunks);
-  if (p.cpg == 6) hipLaunchKernelGGL((pwx_kernel<MTW, WM, 6, WL, XL>), grid, dim3(kThreads), 0, s, a);
-  else hipLaunchKernelGGL((pwx_kernel<MTW, WM, 8, WL, XL>), grid, dim3(kThreads), 0, s, a);
+  if (p.cpg == 6) hipLaunchKernelGGL((pwx_kernel<MTW, WM, 6, WL, XL, XB, YB>), grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL((pwx_kernel<MTW, WM, 8, WL, XL, XB, YB>), grid, dim3(kThreads), 0, s, a);
 }
 
-template <int MTW, int WL, int XL>
+template <int MTW, int WL, int XL, bool XB, bool YB>
 void launch_pwx1(const PwxArgs& a, const PwxPlan& p, hipStream_t s) {
-  if (p.WM == 1) launch_pwx2<MTW, 1, WL, XL>(a, p, s);
-  else if (p.WM == 2) launch_pwx2<MTW, 2, WL, XL>(a, p, s);
-  else launch_pwx2<MTW, 4, WL, XL>(a, p, s);
+  if (p.WM == 1) launch_pwx2<MTW, 1, WL, XL, XB, YB>(a, p, s);
+  else if (p.WM == 2) launch_pwx2<MTW, 2, WL, XL, XB, YB>(a, p, s);
+  else launch_pwx2<MTW, 4, WL, XL, XB, YB>(a, p, s);
 }
 
+// instantiated: fp32 tensors with (3, 3) and (1, 1) levels; bf16-stored activations and / or outputs with (1, 1)
 template <int MTW>
-int launch_pwx(const PwxArgs& a, const PwxPlan& p, int wl, int xl, hipStream_t s) {
-  if (wl == 3 && xl == 3) launch_pwx1<MTW, 3, 3>(a, p, s);
-  else if (wl == 1 && xl == 1) launch_pwx1<MTW, 1, 1>(a, p, s);
+int launch_pwx(const PwxArgs& a, const PwxPlan& p, int wl, int xl, int x_dt, int y_dt, hipStream_t s) {
+  if (wl == 3 && xl == 3 && !x_dt && !y_dt) launch_pwx1<MTW, 3, 3, false, false>(a, p, s);
+  else if (wl == 1 && xl == 1 && !x_dt && !y_dt) launch_pwx1<MTW, 1, 1, false, false>(a, p, s);
+  else if (wl == 1 && xl == 1 && x_dt && !y_dt) launch_pwx1<MTW, 1, 1, true, false>(a, p, s);
+  else if (wl == 1 && xl == 1 && !x_dt && y_dt) launch_pwx1<MTW, 1, 1, false, true>(a, p, s);
+  else if (wl == 1 && xl == 1 && x_dt && y_dt) launch_pwx1<MTW, 1, 1, true, true>(a, p, s);
   else return CIDNET_ERR_ARG;
   return CIDNET_OK;
 }
@@ -409,7 +444,13 @@ int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int
 /* w_levels / x_levels: bf16 levels of the weights / activations that enter the products: (3, 3) or (1, 1) */
 int cidnet_pw_conv_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs, const float* R,
                                  long r_bs, int B, int M, int K, long HW, int w_levels, int x_levels, void* stream) {
-  CIDNET_CHECK_ARG(X && Wprep && Y && B > 0);
+  return cidnet_pw_conv_bf16x3_pre_t(X, CIDNET_F32, x_bs, Wprep, per_sample, Y, CIDNET_F32, y_bs, R, r_bs, B, M, K, HW, w_levels, x_levels, stream);
+}
+
+/* typed activations / output (CIDNET_F32 / CIDNET_BF16; bf16 with (1, 1) levels only): the bf16 mode's 1x1 conv */
+int cidnet_pw_conv_bf16x3_pre_t(const void* X, int x_dt, long x_bs, const float* Wprep, int per_sample, void* Y, int y_dt, long y_bs,
+                                const float* R, long r_bs, int B, int M, int K, long HW, int w_levels, int x_levels, void* stream) {
+  CIDNET_CHECK_ARG(X && Wprep && Y && B > 0 && (x_dt | 1) == 1 && (y_dt | 1) == 1);
   if (!cidnet_pw_conv_bf16x3_supported(M, K, HW)) return CIDNET_ERR_SHAPE;
   CIDNET_CHECK_ARG((reinterpret_cast<uintptr_t>(Wprep) & 15) == 0);
   const PwxPlan p = pwx_plan(M, K, HW);
@@ -418,11 +459,11 @@ int cidnet_pw_conv_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, 
             p.KB, p.MT, p.tiles_per_sample};
   int rc;
   switch (p.MTW) {
-    case 1: rc = launch_pwx<1>(a, p, w_levels, x_levels, s); break;
-    case 2: rc = launch_pwx<2>(a, p, w_levels, x_levels, s); break;
-    case 3: rc = launch_pwx<3>(a, p, w_levels, x_levels, s); break;
-    case 4: rc = launch_pwx<4>(a, p, w_levels, x_levels, s); break;
-    default: rc = launch_pwx<5>(a, p, w_levels, x_levels, s); break;
+    case 1: rc = launch_pwx<1>(a, p, w_levels, x_levels, x_dt, y_dt, s); break;
+    case 2: rc = launch_pwx<2>(a, p, w_levels, x_levels, x_dt, y_dt, s); break;
+    case 3: rc = launch_pwx<3>(a, p, w_levels, x_levels, x_dt, y_dt, s); break;
+    case 4: rc = launch_pwx<4>(a, p, w_levels, x_levels, x_dt, y_dt, s); break;
+    default: rc = launch_pwx<5>(a, p, w_levels, x_levels, x_dt, y_dt, s); break;
   }
   if (rc != CIDNET_OK) return rc;
   CIDNET_LAUNCH_STATUS();

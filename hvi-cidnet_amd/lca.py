@@ -60,6 +60,7 @@ class HV_LCA(nn.Module):
         super().__init__()
         self.gdfn = IEL(dim)
         self.norm = LayerNorm(dim)
+        self.norm.lca_internal = True
         self.ffn = CAB(dim, num_heads, bias)
 
     def forward(self, x, y):
@@ -78,6 +79,7 @@ class I_LCA(nn.Module):
     def __init__(self, dim, num_heads, bias=False):
         super().__init__()
         self.norm = LayerNorm(dim)
+        self.norm.lca_internal = True
         self.gdfn = IEL(dim)
         self.ffn = CAB(dim, num_heads, bias=bias)
 

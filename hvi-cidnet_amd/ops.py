@@ -32,6 +32,18 @@ def _check(*ts):
             raise RuntimeError(f"hvi-cidnet_amd ops are fp32 (got {t.dtype})")
 
 
+def _check_act(*ts):
+    """activations inside an LCA block: fp32, or bf16 in the bf16 mode (STORAGE)"""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("hvi-cidnet_amd ops run only on a ROCm device (got a CPU tensor); "
+                               "there is no CPU fallback -- use the oracle under oracle/ for CPU checks")
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"hvi-cidnet_amd activations are fp32 or bf16 (got {t.dtype})")
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -220,6 +232,17 @@ def _raw(name, *a):
 # kernel still computes in fp32, weights, weight gradients and all other activations stay fp32.  Results then differ from
 # the reference by bf16 rounding of those tensors (~4e-3 relative on a hidden value): a separate, looser tolerance tier.
 STORAGE = {"hidden": torch.float32}
+
+
+def lca_dtype(x):
+    """storage type of the tensors that live INSIDE an LCA block (LayerNorm outputs, the CAB's q / k / v before and after
+    their depthwise convs, the IEL hidden tensors, and all their gradients) for a block whose input is x: bf16 in the bf16
+    mode where the typed LayerNorm kernels cover the shape (CIDNet's 36 / 72 / 144-channel levels), else fp32.  The
+    residual stream between blocks, the conv / resampling activations and every parameter / gradient stay fp32."""
+    if STORAGE["hidden"] == torch.float32 or x.dim() != 4 or x.dtype != torch.float32:
+        return torch.float32
+    B, C, H, W = x.shape
+    return torch.bfloat16 if _raw("cidnet_ln_cf_typed_supported", B, C, H * W) else torch.float32
 
 
 def set_storage_dtype(name):
@@ -411,13 +434,14 @@ def pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B
         pre = _ws(n, x.device)
         prepare(pre)
     lv = MATH["levels"]
-    lib().call("cidnet_pw_conv_bf16x3_pre_lv", _po(x, x_off), x_bs, _p(pre), per_sample, _po(y, y_off), y_bs,
+    # x / y stored as bf16 (bf16 mode, levels == 1): read without conversion / rounded on store; offsets and strides in elements
+    lib().call("cidnet_pw_conv_bf16x3_pre_t", _pe(x, x_off), _dt(x), x_bs, _p(pre), per_sample, _pe(y, y_off), _dt(y), y_bs,
                _po(res, r_off) if res is not None else None, r_bs, B, M, K, HW, lv, lv, _stream())
 
 
 def pw_conv(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res=None, r_off=0, r_bs=0):
     """x / y may be bf16 tensors (offsets and strides in elements)"""
-    if PW_BF16X3["on"] and x.dtype == torch.float32 and y.dtype == torch.float32 \
+    if PW_BF16X3["on"] and ((x.dtype == torch.float32 and y.dtype == torch.float32) or MATH["levels"] == 1) \
             and pw_bf16x3_wins(M, K, HW) \
             and _raw("cidnet_pw_conv_bf16x3_supported", M, K, HW):
         return pw_conv_bf16x3(x, x_off, x_bs, w, w_off, w_bs, w_ms, w_ks, y, y_off, y_bs, B, M, K, HW, res, r_off, r_bs)
@@ -439,7 +463,8 @@ def pw_wgrad(dy, dy_off, dy_bs, x, x_off, x_bs, dw, dw_off, dw_ld, B, M, N, HW, 
 
 
 def dw3x3(inp, w1, w2, csplit, out, B, C, H, W, flip=False, addend=None):
-    lib().call("cidnet_dw3x3", _p(inp), _p(w1), _p(w2), csplit, _p(addend), _p(out), int(flip), B, C, H, W, _stream())
+    """inp / addend / out share one storage type (fp32 or bf16)"""
+    lib().call("cidnet_dw3x3_t", _p(inp), _p(w1), _p(w2), csplit, _p(addend), _p(out), _dt(inp), int(flip), B, C, H, W, _stream())
 
 
 def dw3x3_wgrad(inp, gout, gw1, gw2, csplit, B, C, H, W):
@@ -597,14 +622,14 @@ class LayerNormCFFn(torch.autograd.Function):
     """Reference: LayerNorm.forward (channels_first), net/transformer_utils.py:24-29."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, state=None):
+    def forward(ctx, x, weight, bias, eps, state=None, out_dtype=torch.float32):
         _check(x, weight, bias)
         x = _c(x)
         B, C, H, W = x.shape
-        y = torch.empty_like(x)
+        y = torch.empty_like(x, dtype=out_dtype)
         mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        lib().call("cidnet_ln_cf_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
+        lib().call("cidnet_ln_cf_fwd_t", _p(x), _p(weight), _p(bias), _p(y), _dt(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         _ln_forward_count(ctx, state)
         return y
@@ -614,13 +639,14 @@ class LayerNormCFFn(torch.autograd.Function):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         B, C, H, W = x.shape
         gy = _c(gy)
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw, gb, acc, hand = _ln_param_grads(ctx, weight, bias)
+        # a bf16 gradient (bf16 mode) runs on the fused kernel, which always produces gx
+        gx = torch.empty_like(x) if (ctx.needs_input_grad[0] or gy.dtype == torch.bfloat16) else None
         n = _raw("cidnet_ln_cf_bwd_ws_floats", C)
         ws = _ws(n, x.device)
-        lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), None, _p(gx), _p(gw), _p(gb), int(acc), _p(ws),
-                   ws.numel(), B, C, H * W, _stream())
-        return gx, (gw if hand else None), (gb if hand else None), None, None
+        lib().call("cidnet_ln_cf_bwd_res_t", _p(x), _p(weight), _p(gy), _dt(gy), _p(mean), _p(rstd), None, _p(gx), _p(gw), _p(gb), int(acc),
+                   _p(ws), ws.numel(), B, C, H * W, _stream())
+        return (gx if ctx.needs_input_grad[0] else None), (gw if hand else None), (gb if hand else None), None, None, None
 
 
 class LayerNormResFn(torch.autograd.Function):
@@ -630,14 +656,14 @@ class LayerNormResFn(torch.autograd.Function):
     (cidnet_ln_cf_bwd_res)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, state=None):
+    def forward(ctx, x, weight, bias, eps, state=None, out_dtype=torch.float32):
         _check(x, weight, bias)
         x = _c(x)
         B, C, H, W = x.shape
-        y = torch.empty_like(x)
+        y = torch.empty_like(x, dtype=out_dtype)
         mean = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        lib().call("cidnet_ln_cf_fwd", _p(x), _p(weight), _p(bias), _p(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
+        lib().call("cidnet_ln_cf_fwd_t", _p(x), _p(weight), _p(bias), _p(y), _dt(y), _p(mean), _p(rstd), B, C, H * W, _f(eps), _stream())
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         _ln_forward_count(ctx, state)
         return y, x.view_as(x)
@@ -650,15 +676,15 @@ class LayerNormResFn(torch.autograd.Function):
         if gy is None:                      # only the residual path was used
             if not acc:
                 gw.zero_(); gb.zero_()
-            return gres, (gw if hand else None), (gb if hand else None), None, None
+            return gres, (gw if hand else None), (gb if hand else None), None, None, None
         gy = _c(gy)
         gres = _c(gres) if gres is not None else None
         gx = torch.empty_like(x)
         n = _raw("cidnet_ln_cf_bwd_ws_floats", C)
         ws = _ws(n, x.device)
-        lib().call("cidnet_ln_cf_bwd_res", _p(x), _p(weight), _p(gy), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw), _p(gb), int(acc),
-                   _p(ws), ws.numel(), B, C, H * W, _stream())
-        return gx, (gw if hand else None), (gb if hand else None), None, None
+        lib().call("cidnet_ln_cf_bwd_res_t", _p(x), _p(weight), _p(gy), _dt(gy), _p(mean), _p(rstd), _p(gres), _p(gx), _p(gw), _p(gb),
+                   int(acc), _p(ws), ws.numel(), B, C, H * W, _stream())
+        return gx, (gw if hand else None), (gb if hand else None), None, None, None
 
 
 LN_DUAL = {"on": os.environ.get("CIDNET_LN_DUAL", "1") == "1"}
@@ -732,13 +758,17 @@ class CABResidualFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_res, xn, yn, temperature, wq, wq_dw, wkv, wkv_dw, wp, heads):
-        _check(x_res, xn, yn, temperature, wq, wq_dw, wkv, wkv_dw, wp)
+        _check(x_res, temperature, wq, wq_dw, wkv, wkv_dw, wp)
+        _check_act(xn, yn)
+        if xn.dtype != yn.dtype:
+            raise RuntimeError("CAB: the two normalised inputs must share a storage type")
         x_res, xn, yn = _c(x_res), _c(xn), _c(yn)
         B, C, H, W = xn.shape
         HW = H * W
         dev = xn.device
         ch = C // heads
-        qkv0 = torch.empty((B, 3 * C, H, W), device=dev, dtype=torch.float32)
+        # q | k | v before and after their depthwise convs take the storage type of the normalised inputs (bf16 in the bf16 mode)
+        qkv0 = torch.empty((B, 3 * C, H, W), device=dev, dtype=xn.dtype)
         pw_conv(xn, 0, C * HW, wq, 0, 0, C, 1, qkv0, 0, 3 * C * HW, B, C, C, HW)
         pw_conv(yn, 0, C * HW, wkv, 0, 0, C, 1, qkv0, C * HW, 3 * C * HW, B, 2 * C, C, HW)
         qkv = torch.empty_like(qkv0)
@@ -750,7 +780,7 @@ class CABResidualFn(torch.autograd.Function):
         M = torch.empty((B, C, C), device=dev, dtype=torch.float32)
         n = _raw("cidnet_attn_gram_ws_floats", B, C, heads, HW)
         ws = _ws(n, dev)
-        lib().call("cidnet_attn_fwd", _p(qkv), _p(temperature), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(M), _p(ws),
+        lib().call("cidnet_attn_fwd_t", _p(qkv), _dt(qkv), _p(temperature), _p(wp), _p(attn), _p(shat), _p(nq), _p(nk), _p(M), _p(ws),
                    ws.numel(), B, C, heads, HW, 1, _stream())
         out = torch.empty_like(x_res)
         pw_conv(qkv, 2 * C * HW, 3 * C * HW, M, 0, C * C, C, 1, out, 0, C * HW, B, C, C, HW, res=x_res, r_bs=C * HW)
@@ -817,7 +847,8 @@ class IELFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xn, res, w_in, w_dw, w_dw1, w_dw2, w_out, train=True):
-        _check(xn, res, w_in, w_dw, w_dw1, w_dw2, w_out)
+        _check(res, w_in, w_dw, w_dw1, w_dw2, w_out)
+        _check_act(xn)
         xn = _c(xn)
         res = _c(res) if res is not None else None
         B, C, H, W = xn.shape
@@ -825,7 +856,7 @@ class IELFn(torch.autograd.Function):
         h = w_dw1.shape[0]
         dev = xn.device
         ctx.fused = False
-        if IEL_FUSED["fwd"] and (not train or IEL_FUSED["bwd"]) and _raw("cidnet_iel_fwd_supported", C, h):
+        if IEL_FUSED["fwd"] and xn.dtype == torch.float32 and (not train or IEL_FUSED["bwd"]) and _raw("cidnet_iel_fwd_supported", C, h):
             # tile-resident kernel (csrc/iel.hip): the hidden tensors never reach HBM; u is written only for the backward
             u = torch.empty((B, 2 * h, H, W), device=dev, dtype=torch.float32) if train else None
             out = torch.empty_like(xn)
@@ -836,14 +867,14 @@ class IELFn(torch.autograd.Function):
                 ctx.save_for_backward(xn, u, w_in, w_dw, w_dw1, w_dw2, w_out)
             ctx.has_res = res is not None
             return out
-        hd = STORAGE["hidden"]                             # fp32, or bf16 in the bf16 storage mode
+        hd = STORAGE["hidden"] if STORAGE["hidden"] != torch.float32 else xn.dtype    # fp32, or bf16 in the bf16 mode
         pin = torch.empty((B, 2 * h, H, W), device=dev, dtype=hd)
         pw_conv(xn, 0, C * HW, w_in, 0, 0, C, 1, pin, 0, 2 * h * HW, B, 2 * h, C, HW)
         u = torch.empty_like(pin) if train else None      # inference: u (read only by the backward) is not stored
         gate = torch.empty((B, h, H, W), device=dev, dtype=hd)
         lib().call("cidnet_iel_dw_gate_fwd_t", _p(pin), _p(w_dw), _p(w_dw1), _p(w_dw2), _p(u) if train else None, _p(gate), _dt(pin),
                    B, h, H, W, _stream())
-        out = torch.empty_like(xn)
+        out = torch.empty_like(xn, dtype=torch.float32)    # back on the fp32 residual stream
         pw_conv(gate, 0, h * HW, w_out, 0, 0, h, 1, out, 0, C * HW, B, C, h, HW, res=res, r_bs=C * HW)
         if train:
             ctx.save_for_backward(xn, pin, u, gate, w_in, w_dw, w_dw1, w_dw2, w_out)

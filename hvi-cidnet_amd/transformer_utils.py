@@ -20,12 +20,18 @@ class LayerNorm(nn.Module):
             raise NotImplementedError
         self.normalized_shape = (normalized_shape,)
         self._use = ops.LNUse()            # multi-use bookkeeping (ops.LNUse): in-place summing of this module's gradients
+        # the norm of an LCA block feeds nothing but 1x1 convs (net/LCA.py:22-23,60): in the bf16 mode its OUTPUT is stored
+        # as bf16 (ops.STORAGE); set by HV_LCA / I_LCA, never for the optional norms of the down / up blocks
+        self.lca_internal = False
+
+    def _out_dtype(self, x):
+        return ops.lca_dtype(x) if self.lca_internal else torch.float32
 
     def forward(self, x):
         if self.data_format != "channels_first":
             raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
         return ops.LayerNormCFFn.apply(x, self.weight, self.bias, self.eps,
-                                       self._use if ops.needs_grad(x, self.weight, self.bias) else None)
+                                       self._use if ops.needs_grad(x, self.weight, self.bias) else None, self._out_dtype(x))
 
     def forward_res(self, x):
         """(norm(x), x) for a pre-norm residual block: use the second value as the residual input (see
@@ -33,7 +39,7 @@ class LayerNorm(nn.Module):
         if self.data_format != "channels_first":
             raise NotImplementedError("hvi-cidnet_amd implements the channels_first LayerNorm of the CIDNet hot path")
         return ops.LayerNormResFn.apply(x, self.weight, self.bias, self.eps,
-                                        self._use if ops.needs_grad(x, self.weight, self.bias) else None)
+                                        self._use if ops.needs_grad(x, self.weight, self.bias) else None, self._out_dtype(x))
 
     def forward_dual(self, x, other):
         """(self(x), other(x), x): this module's norm (x-norm of its block; the third value is the block's residual input, as

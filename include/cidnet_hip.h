@@ -30,6 +30,11 @@ extern "C" {
 
 int cidnet_abi_version(void);
 
+/* element-type codes of the typed (`_t`) entry points: a tensor passed as `void*` with an `int <name>_dt` is stored as fp32
+ * or bfloat16; strides and offsets stay in ELEMENTS */
+#define CIDNET_F32 0
+#define CIDNET_BF16 1
+
 /* ---- K1: RGB -> HVI  (RGB_HVI.HVIT, net/HVI_transform.py:16-47; CIDNet.HVIT, net/CIDNet.py:124) --
  * rgb, hvi: (B,3,H,W).  density_k: device pointer to the scalar parameter (read on the device, so
  * the reference's k.item() host sync at :38 disappears).  branch_code (optional, B*H*W bytes):
@@ -70,6 +75,16 @@ long cidnet_ln_cf_bwd_ws_floats(int C);
 int cidnet_ln_cf_bwd(const float* x, const float* weight, const float* gy, const float* mean,
                      const float* rstd, float* gx, float* gw, float* gb, float* ws, long ws_floats,
                      int B, int C, long HW, void* stream);
+/* Typed forms for the bf16 mode: the LayerNorm OUTPUT (it only feeds 1x1 convs, net/LCA.py:22-23,60) and the incoming
+ * gradient (an output of those convs' data-gradient launches) may be stored as bf16; x, the statistics, gx and the
+ * parameter gradients stay fp32.  bf16 only for cidnet_ln_cf_typed_supported shapes (C = 36 / 72 / 144), else
+ * CIDNET_ERR_SHAPE. */
+int cidnet_ln_cf_typed_supported(int B, int C, long HW);
+int cidnet_ln_cf_fwd_t(const float* x, const float* weight, const float* bias, void* y, int y_dt, float* mean, float* rstd,
+                       int B, int C, long HW, float eps, void* stream);
+int cidnet_ln_cf_bwd_res_t(const float* x, const float* weight, const void* gy, int gy_dt, const float* mean,
+                           const float* rstd, const float* addend, float* gx, float* gw, float* gb, int accumulate,
+                           float* ws, long ws_floats, int B, int C, long HW, void* stream);
 /* same, with gx += addend (the gradient that reaches x through the residual branch of the pre-norm block,
  * net/LCA.py:79,80,91,92): saves the separate accumulation pass.  addend may be NULL.  accumulate != 0: gw / gb are
  * added to instead of overwritten -- one LayerNorm module is applied two or three times per LCA (LCA.py:79-80,91-92)
@@ -107,8 +122,6 @@ void cidnet_debug_pw_flags(int flags);
 /* Element-type codes of the `_t` entry points (row J1, bf16 storage mode): a tensor argument declared `void*` with an
  * `int <name>_dt` is fp32 (CIDNET_F32) or bfloat16 (CIDNET_BF16); strides stay in ELEMENTS.  Arithmetic is fp32 in
  * every kernel: bf16 is a storage format of activations / saved tensors (round to nearest even on store). */
-#define CIDNET_F32 0
-#define CIDNET_BF16 1
 int cidnet_pw_conv_t(const void* X, int x_dt, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks, void* Y,
                      int y_dt, long y_bs, const float* R, long r_bs, int B, int M, int K, long HW, void* stream);
 int cidnet_pw_conv(const float* X, long x_bs, const float* Wt, long w_bs, long w_ms, long w_ks,
@@ -143,6 +156,12 @@ int cidnet_pw_conv_bf16x3_pre(const float* X, long x_bs, const float* Wprep, int
 int cidnet_pw_conv_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, int per_sample, float* Y, long y_bs,
                                  const float* R, long r_bs, int B, int M, int K, long HW, int w_levels, int x_levels,
                                  void* stream);
+/* ... with typed activations / output (x_dt, y_dt: CIDNET_F32 / CIDNET_BF16, defined below; strides in elements): a tensor
+ * STORED as bf16 is read without conversion (its one level) / written rounded to nearest; bf16 types need (1, 1) levels.
+ * R stays fp32 (the residual stream). */
+int cidnet_pw_conv_bf16x3_pre_t(const void* X, int x_dt, long x_bs, const float* Wprep, int per_sample, void* Y, int y_dt,
+                                long y_bs, const float* R, long r_bs, int B, int M, int K, long HW, int w_levels,
+                                int x_levels, void* stream);
 long cidnet_pw_conv_bf16x3_prep_blocks(int M, int K);
 int cidnet_pw_conv_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* Backward of a 1x1 convolution Y = W X (W: (M, N) contiguous) in one kernel: gX (B, N, HW) = W^T gY and dW (M, N) = sum over
@@ -185,6 +204,9 @@ void cidnet_debug_dw_rows(int rows);
 #endif
 int cidnet_dw3x3(const float* in, const float* w1, const float* w2, int csplit, const float* addend,
                  float* out, int flip, int B, int C, int H, int W, void* stream);
+/* in / addend / out stored as fp32 or bf16 (one type, dt): the CAB's q / kv depthwise convs in the bf16 mode */
+int cidnet_dw3x3_t(const void* in, const float* w1, const float* w2, int csplit, const void* addend, void* out, int dt,
+                   int flip, int B, int C, int H, int W, void* stream);
 /* ---- K8 fused: tile-resident IEL forward (net/LCA.py:60-67 [+ the residual of I_LCA, LCA.py:92]) -------------
  * out = [res +] W_out * ((tanh(dw1 u1) + u1) * (tanh(dw2 u2) + u2)),  [u1; u2] = dw(W_in * xn), in ONE kernel: the
  * hidden tensors live in LDS only (csrc/iel.hip).  xn, res, out: (B,C,H,W); w_in (2h,C), w_dw (2h,1,3,3),
@@ -318,6 +340,10 @@ long cidnet_attn_gram_ws_floats(int B, int C, int heads, long HW);
 int cidnet_attn_fwd(const float* qkv, const float* temperature, const float* Wp, float* attn,
                     float* shat, float* nq, float* nk, float* M, float* ws, long ws_floats, int B,
                     int C, int heads, long HW, int normalize, void* stream);
+/* qkv stored as fp32 or bf16 (qkv_dt: CIDNET_F32 / CIDNET_BF16); the Gram products stay on the fp32 MFMA */
+int cidnet_attn_fwd_t(const void* qkv, int qkv_dt, const float* temperature, const float* Wp, float* attn, float* shat,
+                      float* nq, float* nk, float* M, float* ws, long ws_floats, int B, int C, int heads, long HW,
+                      int normalize, void* stream);
 /* From dM (B,C,C): per-sample dWp_b (B,C,C), dT_b (B,heads), and Wqk (B,2C,2C) with
  * [dq;dk][b] = Wqk[b] * [q;k][b]  (softmax + L2-normalisation backward folded). */
 int cidnet_attn_bwd(const float* dM, const float* Wp, const float* attn, const float* shat,

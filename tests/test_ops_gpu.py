@@ -701,3 +701,30 @@ def test_pw_wgrad_one_level(dev, B, M, N, HW, dts):
         ops.set_math_levels(3)
     err = (dw.double().cpu() - ref).abs().max().item()
     assert err <= 1e-5 * ref.abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("B,M,K,HW,res", [(2, 36, 95, 60 * 40, True), (1, 190, 36, 75 * 50, False), (2, 72, 191, 1001, True), (1, 144, 383, 130, False)])
+@pytest.mark.parametrize("xb,yb", [(True, False), (False, True), (True, True)])
+def test_pw_conv_bf16_typed_tensors(dev, B, M, K, HW, res, xb, yb):
+    """cidnet_pw_conv_bf16x3_pre_t: activations and / or output STORED as bf16 (the bf16 mode's IEL / CAB tensors).  A bf16
+    input is read without conversion (v_perm packs the channel pairs); a bf16 output is the fp32 result rounded to nearest.
+    Reference: fp64 product of the bf16-rounded operands, then the same rounding of the output."""
+    from hvi_cidnet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + K + HW)
+    x = torch.randn(B, K, HW, device=dev, generator=g)
+    w = torch.randn(M, K, device=dev, generator=g) / K ** 0.5
+    r = torch.randn(B, M, HW, device=dev, generator=g) if res else None
+    ref = torch.matmul(_bf16_round(w).cpu(), _bf16_round(x).cpu())
+    if res:
+        ref = ref + r.double().cpu()
+    xt = x.to(torch.bfloat16) if xb else x
+    y = torch.full((B, M, HW), float("nan"), device=dev, dtype=torch.bfloat16 if yb else torch.float32)
+    ops.set_math_levels(1)
+    try:
+        ops.pw_conv(xt, 0, K * HW, w, 0, 0, K, 1, y, 0, M * HW, B, M, K, HW, res=r, r_bs=M * HW)
+    finally:
+        ops.set_math_levels(3)
+    assert not torch.isnan(y.float()).any()
+    err = (y.double().cpu() - ref).abs().max().item()
+    bar = (2.0 ** -8 if yb else 3e-6) * ref.abs().max().item() + 1e-6          # bf16 store: half an ulp of the largest value
+    assert err <= bar, (err, bar)
