@@ -164,7 +164,7 @@ class DataParallelTrainer:
             for st in ln_uses:
                 st.acc, st.fwd, st.bwd, st.probe = False, 0, 0, [0, 0]
         self.model.zero_grad(set_to_none=True)
-        loss = self.loss_fn(self.model(x), gt)
+        loss = self._loss(self.model(x), gt, x)
         loss.backward()
         for h in hooks:
             h.remove()
@@ -355,10 +355,18 @@ class DataParallelTrainer:
         import contextlib
         return contextlib.nullcontext()
 
+    def _loss(self, out, gt, x):
+        """loss_fn(model(x), gt); a loss function with a true `wants_input` attribute (losses.CIDNetLoss: the TNSM noise terms
+        compare the output with the network input, train_tnsm.py:69) also gets the input as im1=x.  Tuple results of the
+        model (CIDNet_TNSM in train mode) are handed to the loss function as they are."""
+        if getattr(self.loss_fn, "wants_input", False):
+            return self.loss_fn(out, gt, im1=x)
+        return self.loss_fn(out, gt)
+
     def _fwd_bwd(self, x, gt):
         with self._pass_scope():
             self._begin_pass(x)
-            loss = self.loss_fn(self.model(x), gt)
+            loss = self._loss(self.model(x), gt, x)
             self._backward(loss)
             self._end_pass()
         return loss

@@ -173,13 +173,26 @@ class CIDNetLoss(nn.Module):
             t = t + self.p_weight * self.perceptual(a, b)[0]
         return t
 
+    # dp.DataParallelTrainer passes the step's input as `im1=` to a loss function with this attribute
+    wants_input = True
+
     def forward(self, output_rgb, gt_rgb, noise_map=None, im1=None):
-        """`noise_map`, `im1`: the second result of CIDNet_TNSM.forward in train mode and the network input; with
-        tnsm_weight > 0 they add train_tnsm.py:68-72's  tnsm_weight * (noise_consistency_loss + noise_smoothing_loss)."""
+        """`output_rgb`: the model's result -- a tensor, or CIDNet_TNSM's train-mode pair (rgb, fused noise map), which is
+        unpacked here.  `noise_map`, `im1`: that second result and the RAW low-light image -- train_tnsm.py:69 uses im1 as
+        loaded, before the optional `im1 ** gamma` the network is fed with (:55) -- with tnsm_weight > 0 they add
+        train_tnsm.py:68-72's  tnsm_weight * (noise_consistency_loss + noise_smoothing_loss).  A positive tnsm_weight without
+        a noise map raises: the reference's default is tnsm_weight = 1 (options.py:61) and silently training without the
+        terms would be a different objective."""
+        if isinstance(output_rgb, (tuple, list)):
+            output_rgb, model_noise = output_rgb[0], output_rgb[1]
+            noise_map = model_noise if noise_map is None else noise_map
+        if self.tnsm_weight > 0 and noise_map is None:
+            raise ValueError("CIDNetLoss(tnsm_weight > 0) needs the fused noise map: pass CIDNet_TNSM's train-mode result (rgb, noise) "
+                             "or noise_map=...; a model in eval mode returns (rgb, None)")
         loss_hvi = self._terms(self._hvit(output_rgb), self._hvit(gt_rgb))
         loss_rgb = self._terms(output_rgb, gt_rgb)
         loss = loss_rgb + self.hvi_weight * loss_hvi
-        if self.tnsm_weight > 0 and noise_map is not None:
+        if self.tnsm_weight > 0:
             if im1 is None:
                 raise ValueError("CIDNetLoss: the TNSM noise terms need the network input im1 (train_tnsm.py:69)")
             loss = loss + tnsm_noise_loss(noise_map, output_rgb, im1, self.tnsm_weight)

@@ -239,7 +239,9 @@ def lca_dtype(x):
     their depthwise convs, the IEL hidden tensors, and all their gradients) for a block whose input is x: bf16 in the bf16
     mode where the typed LayerNorm kernels cover the shape (CIDNet's 36 / 72 / 144-channel levels), else fp32.  The
     residual stream between blocks, the conv / resampling activations and every parameter / gradient stay fp32."""
-    if STORAGE["hidden"] == torch.float32 or x.dim() != 4 or x.dtype != torch.float32:
+    # (set_storage_dtype("bf16") alone -- bf16 storage with fp32-exact products -- keeps to the IEL hidden tensors: the fp32-MFMA
+    # 1x1 kernel it then runs on has no bf16-in / bf16-out form)
+    if STORAGE["hidden"] == torch.float32 or MATH["levels"] != 1 or x.dim() != 4 or x.dtype != torch.float32:
         return torch.float32
     B, C, H, W = x.shape
     return torch.bfloat16 if _raw("cidnet_ln_cf_typed_supported", B, C, H * W) else torch.float32

@@ -728,3 +728,63 @@ def test_pw_conv_bf16_typed_tensors(dev, B, M, K, HW, res, xb, yb):
     err = (y.double().cpu() - ref).abs().max().item()
     bar = (2.0 ** -8 if yb else 3e-6) * ref.abs().max().item() + 1e-6          # bf16 store: half an ulp of the largest value
     assert err <= bar, (err, bar)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 36, 8, 12), (1, 72, 10, 15), (2, 144, 5, 7), (1, 36, 25, 40)])
+def test_layernorm_bf16_typed_output_and_gradient(dev, B, C, H, W):
+    """cidnet_ln_cf_fwd_t / _bwd_res_t: in the bf16 mode the LayerNorm of an LCA block writes its OUTPUT as bf16 (the fp32
+    result rounded to nearest) and reads the incoming gradient as bf16; x, statistics, gx and the parameter gradients stay
+    fp32.  Against the fp32 kernels on the same (bf16-representable) gradient: bit-equal arithmetic, so equal results."""
+    from hvi_cidnet_amd import ops
+    if not ops._raw("cidnet_ln_cf_typed_supported", B, C, H * W):
+        pytest.skip("shape without typed LayerNorm kernels")
+    x = rnd(61, (B, C, H, W), 2.0).to(dev)
+    w, b = (1.0 + 0.3 * rnd(62, (C,))).to(dev), (0.2 * rnd(63, (C,))).to(dev)
+    gy = rnd(64, (B, C, H, W)).to(dev).to(torch.bfloat16)            # a bf16-representable gradient
+    res = rnd(65, (B, C, H, W)).to(dev)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y, xp = ops.LayerNormResFn.apply(xr, wr, br, 1e-6, None, dt)
+        assert y.dtype == dt
+        torch.autograd.backward([y, xp], [gy.to(dt), res])
+        outs[dt] = (y, xr.grad, wr.grad, br.grad)
+    y32, yh = outs[torch.float32][0], outs[torch.bfloat16][0]
+    assert torch.equal(yh, y32.to(torch.bfloat16))                    # the same value, rounded on store
+    for a, b_ in zip(outs[torch.float32][1:], outs[torch.bfloat16][1:]):
+        assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 12, 9, 13), (1, 108, 16, 24), (1, 7, 3, 3), (2, 36, 40, 75)])
+def test_dw3x3_bf16_typed(dev, B, C, H, W):
+    """cidnet_dw3x3_t with bf16-stored input / output: the fp32 stencil on the bf16 values, rounded on store"""
+    from hvi_cidnet_amd import ops
+    x = rnd(71, (B, C, H, W)).to(dev).to(torch.bfloat16)
+    w = rnd(72, (C, 1, 3, 3), 0.5).to(dev)
+    y32 = torch.empty((B, C, H, W), device=dev)
+    yh = torch.full((B, C, H, W), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.dw3x3(x.float(), w, None, C, y32, B, C, H, W)
+    ops.dw3x3(x, w, None, C, yh, B, C, H, W)
+    assert torch.equal(yh, y32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,C,heads,HW", [(2, 36, 2, 60 * 40), (1, 72, 4, 1001), (2, 144, 8, 130)])
+def test_attn_fwd_bf16_typed_qkv(dev, B, C, heads, HW):
+    """cidnet_attn_fwd_t: q | k | v stored as bf16 are read as the same values the fp32 entry point reads from their fp32 copies"""
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd._lib import lib
+    ch = C // heads
+    qkv = rnd(81, (B, 3 * C, HW)).to(dev).to(torch.bfloat16)
+    T = (1.0 + 0.1 * rnd(82, (heads, 1, 1))).to(dev)
+    wp = rnd(83, (C, C), 0.3).to(dev)
+    res = []
+    for t in (qkv.float().contiguous(), qkv):
+        attn = torch.empty((B, heads, ch, ch), device=dev); shat = torch.empty_like(attn)
+        nq = torch.empty((B, C), device=dev); nk = torch.empty_like(nq); M = torch.empty((B, C, C), device=dev)
+        n = ops._raw("cidnet_attn_gram_ws_floats", B, C, heads, HW)
+        ws = torch.empty(n, device=dev)
+        lib().call("cidnet_attn_fwd_t", ops._p(t), ops._dt(t), ops._p(T), ops._p(wp), ops._p(attn), ops._p(shat), ops._p(nq), ops._p(nk),
+                   ops._p(M), ops._p(ws), ws.numel(), B, C, heads, HW, 1, ops._stream())
+        res.append((attn, shat, nq, nk, M))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)

@@ -280,3 +280,40 @@ def test_trainer_prepared_weights_bit_identical(dev):
         ops.enable_prepared_weights(False)
         ops.set_grad_arena(None, None)
         ops.enable_wgrad_stream(False)
+
+
+def test_trainer_with_tnsm_model_and_its_objective(dev):
+    """CIDNet_TNSM in train mode returns (rgb, fused noise map): DataParallelTrainer hands the pair and the step's input to
+    losses.CIDNetLoss(tnsm_weight=1) (train_tnsm.py:56-72; options.py:61), whose noise terms then reach the noise branch;
+    without a noise map a positive tnsm_weight raises instead of silently dropping the terms."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd import ops
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    chans, shape = (12, 12, 24, 48), (2, 3, 32, 48)
+    torch.manual_seed(3)
+    m = P.CIDNet_TNSM(channels=list(chans)).to(dev).train()
+    x = O.synthetic_batch(51, shape).to(dev)
+    gt = O.synthetic_batch(52, shape).to(dev)
+    lf = P.CIDNetLoss(m, tnsm_weight=1.0).to(dev)
+    try:
+        with pytest.raises(ValueError, match="noise map"):
+            lf(torch.rand(shape, device=dev), gt)
+        # manual composition of the same objective
+        rgb, noise = m(x)
+        manual = P.CIDNetLoss(m, tnsm_weight=0.0).to(dev)(rgb, gt) + P.tnsm_noise_loss(noise, rgb, x, 1.0)
+        tr = DataParallelTrainer(m, lr=1e-4, loss_fn=lf)
+        loss = tr.forward_backward(x, gt)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - manual.item()) <= 1e-5 * abs(manual.item()) + 1e-6
+        names = {id(p): n for n, p in m.named_parameters()}
+        noise_params = [p for p in tr.params if "noise_map_generator" in names[id(p)] and id(p) in tr._slices
+                        and not names[id(p)].startswith("I_TNSM5")]
+        assert noise_params
+        off, n = tr._slices[id(noise_params[0])]
+        assert tr.flat_g[off:off + n].abs().max().item() > 0
+        l2 = tr.step(x, gt)
+        assert torch.isfinite(l2)
+    finally:
+        ops.clear_prepared_weights()
+        ops.set_grad_arena(None, None)
+        ops.enable_wgrad_stream(False)
