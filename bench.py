@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the IEL chain's hidden tensors (arithmetic is fp32 either way); f32 is the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-inference-leg", action="store_true", help="skip the 32x3x1024x1024 inference measurement (configs[3])")
+    ap.add_argument("--no-inference-leg", action="store_true",
+                    help="skip the legs after the timed region: the bf16-mode step (configs[2]), 32x3x1024x1024 inference (configs[3]), the variants (configs[4])")
     ap.add_argument("--no-prepared-weights", action="store_true", help="A/B: prepare the bf16x3 weight operands per launch (as a plain model(x) call does)")
     ap.add_argument("--no-variants", action="store_true", help="skip the MSSA / TNSM bs=16 measurement (configs[4])")
     ap.add_argument("--op-table", action="store_true", help="print per-entry-point time shares to stderr")
@@ -270,6 +271,71 @@ def inference_1024(dev, world=1, local=0):
             "phvit_GBs": round(24.0 * px / (ms_p * 1e-3) / 1e9, 1), "hbm_peak_GBs": PEAK_HBM_GBS, "alg_bytes_per_px": 24}
 
 
+def settle(trainer, x, gt, dev, world=1, max_steps=12):
+    """Set-up, not warm-up: the trainer's first steps build its buckets / gradient arena and grow the caching allocator to
+    the footprint of three queued steps (the host runs ahead of the GPU, see dp.DataParallelTrainer); a step that still
+    has to hipMalloc costs 60-80 ms on the host -- and hundreds of ms once the queue is deep.  Run un-synchronised steps until
+    three in a row add no device segment (N > 1: a fixed count, every step holds a collective)."""
+    segs = lambda: torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    quiet = 0
+    for _ in range(max_steps if world == 1 else 8):
+        before = segs()
+        trainer.step(x, gt)
+        quiet = quiet + 1 if segs() == before else 0
+        if quiet >= 3 and world == 1:
+            break
+    torch.cuda.synchronize()
+
+
+def bf16_mode_leg(a, dev, world, local, rank, f32_ms):
+    """configs[2]'s numeric mode on the SAME box right after the fp32 timed region: P.set_precision("bf16") -- convolution
+    operands rounded to bf16 on the matrix cores (one product per term, fp32 accumulation) and the LCA-internal tensors
+    stored as bf16 -- same step (fwd + L1 + bwd + gradient all-reduce + fused Adam), same batch per GPU, all ranks."""
+    import hvi_cidnet_amd as P
+    from hvi_cidnet_amd.dp import DataParallelTrainer
+    P.set_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        model = P.CIDNet().to(dev)
+        model.two_streams = not a.single_stream
+        tr = DataParallelTrainer(model, lr=1e-4, n_buckets=4, wgrad_stream=not (a.no_wgrad_stream or a.single_stream))
+        g = torch.Generator(device=dev)
+        g.manual_seed(1000 + rank)
+        x = torch.rand((a.batch, 3, a.height, a.width), device=dev, generator=g)
+        gt = torch.rand((a.batch, 3, a.height, a.width), device=dev, generator=g)
+        settle(tr, x, gt, dev, world)
+        for _ in range(3):
+            tr.step(x, gt)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = tr.step(x, gt)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        lossv = float(loss.item())
+        del tr, model
+    finally:
+        P.set_precision("f32")
+        from hvi_cidnet_amd import ops
+        ops.set_grad_arena(None, None)
+        ops.clear_prepared_weights()
+        torch.cuda.empty_cache()
+    ms = 1e3 * dt / n
+    return {"workload": f"the same step in the bf16 mode (BASELINE.json configs[2]'s numeric type), bs={a.batch}/GPU, {world} rank(s)",
+            "images_per_s": round(world * a.batch * n / dt, 1), "ms_per_step": round(ms, 3), "steps": n,
+            "vs_f32_line": round(f32_ms / ms, 3), "loss": round(lossv, 6),
+            "dtype": "bf16 matrix-core operands, fp32 accumulation; bf16 storage of LayerNorm outputs, q/k/v, IEL hidden tensors and their gradients"}
+
+
 def variants_bs16(dev):
     """configs[4]: the MSSA and TNSM variants, fwd + L1 (+ 0.1 mean(noise map) for TNSM, so that its noise branch trains) +
     bwd + fused Adam at bs=16 3x400x600 on one GPU, measured after the timed region (rank 0)."""
@@ -287,10 +353,11 @@ def variants_bs16(dev):
         m = ctor().to(dev)
         lf = (lambda y, t: ops.L1LossFn.apply(y[0], t) + 0.1 * y[1].mean()) if tnsm else None
         tr = DataParallelTrainer(m, lr=1e-4, loss_fn=lf)
-        for _ in range(3):
+        settle(tr, x, gt, dev)
+        for _ in range(2):
             tr.step(x, gt)
         torch.cuda.synchronize()
-        n = 5
+        n = 6
         t0 = time.perf_counter()
         for _ in range(n):
             tr.step(x, gt)
@@ -348,17 +415,7 @@ def main():
             dist.barrier(device_ids=[local])
             torch.cuda.synchronize()
 
-    # Set-up, not warm-up: the trainer's first steps build its buckets / gradient arena and grow the caching allocator to
-    # the footprint of three queued steps (the host runs ahead of the GPU, see dp.DataParallelTrainer); a step that still
-    # has to hipMalloc costs 60-80 ms on the host.  Run un-synchronised steps until a step adds no device segment.
-    segs = lambda: torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-    quiet = 0
-    for _ in range(12 if world == 1 else 8):           # every step holds a collective: all ranks must run the same number
-        before = segs()
-        trainer.step(x, gt)
-        quiet = quiet + 1 if segs() == before else 0
-        if quiet >= 3 and world == 1:
-            break
+    settle(trainer, x, gt, dev, world)                  # set-up steps (allocator footprint), see settle()
     sync()
     for _ in range(max(a.warmup, 1)):
         loss = trainer.step(x, gt)
@@ -482,13 +539,15 @@ def main():
                     "ms_per_step": round(hb_ms / 2, 3), "storage": a.dtype}
         roof["whole_step"] = whole_step_roofline(a, 1e3 * dt / a.steps)
     # the 1024x1024 inference leg runs on EVERY rank (north_star: both sizes at 1/2/4/8 GPUs); the variants on rank 0 at N = 1
-    infer = variants = None
+    infer = variants = bf16 = None
     default_cfg = (a.height, a.width, a.batch) == (400, 600, 8)
     if not a.no_inference_leg and default_cfg:
         del trainer
         _ops.set_grad_arena(None, None)
         _ops.clear_prepared_weights()
         torch.cuda.empty_cache()
+        if a.dtype == "f32" and not a.full_loss:
+            bf16 = bf16_mode_leg(a, dev, world, local, rank, 1e3 * dt / a.steps)
         infer = inference_1024(dev, world, local)
         if world == 1 and not a.no_variants:
             variants = variants_bs16(dev)
@@ -507,6 +566,7 @@ def main():
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1), "streams": 1 if a.single_stream else (2 if a.no_wgrad_stream else 3), "loss": round(lossv, 6)},
             "roofline": roof if a.dtype == "f32" else dict(roof_hbm, mfma_conv3=roof), "roofline_pw": roof_pw, "roofline_hbm": roof_hbm,
             "cpu_baseline": cpu,
+            "bf16_mode": bf16,
             "inference_1024": infer,
             "variants_bs16": variants,
         }
