@@ -265,7 +265,8 @@ def inference_1024(dev, world=1, local=0):
         t = torch.tensor([ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_all = t.item()
-    return {"workload": f"CIDNet inference 32x3x1024x1024 fp32 per GPU (BASELINE.json configs[3]), {world} rank(s)",
+    prec = "fp32" if ops.MATH["levels"] == 3 else "bf16 mode"
+    return {"workload": f"CIDNet inference 32x3x1024x1024 {prec} per GPU (BASELINE.json configs[3]), {world} rank(s)",
             "images_per_s": round(world * B / (ms_all * 1e-3), 1), "n_gpus": world, "ms_per_batch": round(ms_all, 2),
             "rank0_images_per_s": round(B / (ms * 1e-3), 1), "hvit_GBs": round(24.0 * px / (ms_h * 1e-3) / 1e9, 1),
             "phvit_GBs": round(24.0 * px / (ms_p * 1e-3) / 1e9, 1), "hbm_peak_GBs": PEAK_HBM_GBS, "alg_bytes_per_px": 24}
@@ -343,7 +344,8 @@ def variants_bs16(dev):
     from hvi_cidnet_amd.dp import DataParallelTrainer
     from hvi_cidnet_amd import ops
     B = 16
-    out = {"workload": "CIDNet_MSSA / CIDNet_TNSM fwd+bwd bs=16 3x400x600 fp32 (BASELINE.json configs[4])", "step": "fwd + L1 + bwd + fused Adam"}
+    prec = "fp32" if ops.MATH["levels"] == 3 else "bf16 mode"
+    out = {"workload": f"CIDNet_MSSA / CIDNet_TNSM fwd+bwd bs=16 3x400x600 {prec} (BASELINE.json configs[4])", "step": "fwd + L1 + bwd + fused Adam"}
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     x = torch.rand((B, 3, 400, 600), device=dev, generator=g)
@@ -576,7 +578,7 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_TRAFFIC_FILE = "profiles/r04_d_pmc_traffic_by_family.json"
+PMC_TRAFFIC_FILE = "profiles/r04_m_pmc_traffic_by_family.json"
 
 
 def pmc_traffic(family):
