@@ -73,6 +73,16 @@ __device__ __forceinline__ void sincos_tab(const float2* T, float x, float& s, f
   s = fmaf(t.y, cd, t.x * sd);
 }
 
+// a / b for a normal positive b: hardware reciprocal + one Newton step (<= 1.5 ulp of the quotient, sign exact).  The three
+// quotients of HVIT feed VALUES only (hue, saturation: abs error < 1e-7 of a quantity in [0, 1]); every mask / arg-max
+// decision of net/HVI_transform.py:21-31 is a comparison of the inputs themselves and stays bit-exact.  An IEEE division is
+// ~10 VALU instructions, and at ~150 per pixel the kernel is VALU-bound, not HBM-bound.
+__device__ __forceinline__ float div_fast(float a, float b) {
+  float x = __builtin_amdgcn_rcpf(b);
+  x = fmaf(fmaf(-b, x, 1.0f), x, x);
+  return a * x;
+}
+
 struct HvitPx {
   float value, mn, d, num, hue, sat, sn, csn, base, cs, ch, cv;
   int branch;   // 0 gray, 1 R, 2 G, 3 B   (net/HVI_transform.py:23-27)
@@ -90,18 +100,17 @@ __device__ __forceinline__ HvitPx hvit_px(float r, float g, float b, float k, co
   float hue6;
   if (r == o.value) {                 // R mask is assigned last in the reference => wins ties
     o.branch = 1; o.num = g - b;
-    float t = 0.0f + o.num / o.d;
-    hue6 = (t < 0.f) ? t + 6.0f : t;  // torch.remainder(t, 6) for |t| < 6
   } else if (g == o.value) {
     o.branch = 2; o.num = b - r;
-    hue6 = 2.0f + o.num / o.d;
   } else {
     o.branch = 3; o.num = r - g;
-    hue6 = 4.0f + o.num / o.d;
   }
+  const float t = div_fast(o.num, o.d);
+  if (o.branch == 1) hue6 = (t < 0.f) ? t + 6.0f : t;          // torch.remainder(t, 6) for |t| < 6
+  else hue6 = (o.branch == 2 ? 2.0f : 4.0f) + t;
   if (o.mn == o.value) { o.branch = 0; hue6 = 0.f; }
-  o.hue = hue6 / 6.0f;
-  o.sat = (o.value - o.mn) / (o.value + kEps);
+  o.hue = hue6 * 0.166666672f;                                   // / 6 (value only: <= 1 ulp)
+  o.sat = div_fast(o.value - o.mn, o.value + kEps);
   if (o.value == 0.f) o.sat = 0.f;
   const float xs = (o.value * 0.5f) * kPi;
   sincos_tab(T, xs, o.sn, o.csn);

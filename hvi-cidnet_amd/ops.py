@@ -52,8 +52,21 @@ def _p(t):
     return _vp(t.data_ptr()) if t is not None else None
 
 
+# torch.cuda.current_stream() builds a Stream object through three Python layers (~8 us; ~500 calls per training step = a
+# quarter of the host's enqueue time).  The raw handle comes from one C call; the Python form stays as the fallback.
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_handle():
+    """hipStream_t of the current stream of the current device, as an int"""
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return _RAW_STREAM(_CUR_DEVICE())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    return _vp(_stream_handle())
 
 
 def _f(x):
@@ -164,7 +177,7 @@ _WS = {}
 def _ws(n_floats, device):
     """Stream-ordered scratch buffer (grown on demand, reused by consecutive launches); one per stream,
     because the two CIDNet branches may run on two streams concurrently."""
-    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.type, device.index, _stream_handle())
     t = _WS.get(key)
     if t is None or t.numel() < n_floats:
         t = torch.empty(max(int(n_floats), 1 << 20), device=device, dtype=torch.float32)
@@ -536,7 +549,8 @@ def conv3x3_wgrad(dy, x, dw, B, M, N, H, W, replicate=False, x_bs=None):
 
 
 def bilinear_bwd(dout, din, B, C, Hi, Wi, Ho, Wo):
-    if torch.cuda.is_current_stream_capturing():               # no synchronisation inside a capture: tables per call
+    if _BILINEAR_TABS.get((dout.device.type, dout.device.index, Hi, Wi, Ho, Wo)) is None and torch.cuda.is_current_stream_capturing():
+        # first use of a shape inside a capture: no synchronisation possible there, tables per call
         n = _raw("cidnet_bilinear_bwd_ws_floats", Hi, Wi)
         ws = _ws(n, dout.device)
         lib().call("cidnet_bilinear_bwd", _p(dout), _p(din), _p(ws), ws.numel(), B, C, Hi, Wi, Ho, Wo, _stream())
