@@ -43,13 +43,15 @@ def _model():
     return m.to("cuda:0")
 
 
-def _worker(rank, world, port, per_rank, q):
+def _worker(rank, world, port, per_rank, q, precision="f32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hvi_cidnet_amd.dp import DataParallelTrainer
+    import hvi_cidnet_amd as P
+    P.set_precision(precision)
     m = _model()
     tr = DataParallelTrainer(m, lr=1e-4, n_buckets=4)
     x, gt = _data(world, per_rank)
@@ -67,14 +69,18 @@ def _worker(rank, world, port, per_rank, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_match_single_process():
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_two_ranks_on_one_gpu_match_single_process(precision):
+    """precision = "bf16": BASELINE.json configs[2]'s numeric mode (bf16 matrix-core operands, bf16 storage of the LCA-internal
+    tensors) through the same two-rank path: every sample's arithmetic is independent of the batch it sits in, so the
+    reduced mean gradient still equals the single-process gradient on the concatenated batch to fp32 summation order."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     world, per_rank = 2, 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q, precision)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -90,11 +96,20 @@ def test_two_ranks_on_one_gpu_match_single_process():
     # single process, concatenated batch (mean loss over the global batch = mean of the per-rank means)
     sys.path.insert(0, ROOT)
     from hvi_cidnet_amd.dp import DataParallelTrainer
-    m = _model()
-    tr = DataParallelTrainer(m, lr=1e-4, n_buckets=4)
-    x, gt = _data(world, per_rank)
-    tr.forward_backward(x.cuda(), gt.cuda())
-    torch.cuda.synchronize()
-    ref = tr.flat_g[:tr.n_live].cpu()
+    from hvi_cidnet_amd import ops
+    import hvi_cidnet_amd as P
+    P.set_precision(precision)
+    try:
+        m = _model()
+        tr = DataParallelTrainer(m, lr=1e-4, n_buckets=4)
+        x, gt = _data(world, per_rank)
+        tr.forward_backward(x.cuda(), gt.cuda())
+        torch.cuda.synchronize()
+        ref = tr.flat_g[:tr.n_live].cpu()
+    finally:
+        P.set_precision("f32")
+        ops.clear_prepared_weights()
+        ops.set_grad_arena(None, None)
+        ops.enable_wgrad_stream(False)
     d = (res[0][0] - ref).abs().max().item()
     assert d <= 2e-5 * ref.abs().max().item() + 1e-9, (d, ref.abs().max().item())
