@@ -43,3 +43,20 @@ for s in range(max(1, len(adam) - steps), len(adam)):
     print(f"step {s}: wall {1e-6*tot:6.2f} ms  " + "  ".join(f"{k}: {1e-6*cls[k]:5.2f}" for k in ("idle", "<64", "<256", "<1024", ">=1024")) + f"  launches {len(seg)}")
     print("   busy per queue: " + "  ".join(f"{q}: {1e-6*v:5.2f}" for q, v in sorted(qbusy.items())))
     print("   under-filled (<256 workgroups) time by kernel: " + ", ".join(f"{k} {1e-6*v:.2f}" for k, v in owner.most_common(12)))
+
+# ---- idle gaps of the last step: which kernel ended before, which started after ----
+if len(adam) >= 4:
+    s = len(adam) - 3                      # the last three-stream step (the two after it are the instrumented single-stream ones)
+    seg = ev[adam[s - 1] + 1:adam[s] + 1]
+    cur_end, cur_name, gaps = seg[0][0], "(start)", []
+    for a, b, name, blk, q in seg:
+        if a > cur_end:
+            gaps.append((a - cur_end, cur_name, short(name), q))
+        if b > cur_end:
+            cur_end, cur_name = b, short(name)
+    agg = collections.Counter(); cnt = collections.Counter()
+    for g, before, after, q in gaps:
+        agg[(before, after)] += g; cnt[(before, after)] += 1
+    print(f"idle gaps of step {s}: {len(gaps)} gaps, {1e-6 * sum(g for g, *_ in gaps):.2f} ms; largest contributors (ended before -> started after):")
+    for (before, after), v in agg.most_common(25):
+        print(f"   {1e-3 * v:7.1f} us in {cnt[(before, after)]:3d}:  {before[:48]:48s} -> {after[:48]}")
