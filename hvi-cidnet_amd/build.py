@@ -33,7 +33,6 @@ PER_FILE = {"hvi.hip": ["-ffp-contract=off"], "dw.hip": ["-fno-slp-vectorize"] i
             "iel.hip": ["-fno-slp-vectorize"],
             "conv3x.hip": ["-fno-slp-vectorize", *os.environ.get("CIDNET_C3X_FLAGS", "").split()],
             "pwx.hip": ["-fno-slp-vectorize"],
-            "conv3p.hip": ["-fno-slp-vectorize"],
             "conv3xw.hip": ["-fno-slp-vectorize"],
             "pwb.hip": ["-fno-slp-vectorize"],
             "conv3_thin.hip": os.environ.get("CIDNET_THIN_FLAGS", "").split()}

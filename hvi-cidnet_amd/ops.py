@@ -317,7 +317,7 @@ class _Prepared:
 
 _PREP = {"on": False, "entries": {}, "tables": {}, "stats": [0, 0]}
 # kernel families with a prepared weight operand: cache kind -> prefix of their _prep / _prep_blocks / _prep_batch entry points
-_PREP_FAMILY = {"pw": "cidnet_pw_conv_bf16x3", "c3": "cidnet_conv3x3_bf16x3", "c3p": "cidnet_conv3x3_bf16_direct"}
+_PREP_FAMILY = {"pw": "cidnet_pw_conv_bf16x3", "c3": "cidnet_conv3x3_bf16x3"}
 _PREP_MAX_ENTRIES = 1024
 
 
@@ -502,28 +502,12 @@ def dw3x3_bwd(inp, gout, w1, w2, csplit, gin, gw1, gw2, B, C, H, W, addend=None)
 # BF16 matrix cores with exact three-way split operands (csrc/conv3x.hip: results within fp32 rounding of the fp32-MFMA
 # kernel, error against fp64 equal or smaller).  CIDNET_CONV3_BF16X3=0 selects the fp32-MFMA kernel (csrc/conv3.hip).
 CONV3_BF16X3 = {"on": os.environ.get("CIDNET_CONV3_BF16X3", "1") == "1"}
-# bf16 mode only: the LDS-free form (csrc/conv3p.hip); CIDNET_CONV3_DIRECT=0 keeps the one-level form of conv3x.hip
-CONV3_DIRECT = {"on": os.environ.get("CIDNET_CONV3_DIRECT", "1") == "1"}
 
 
 def conv3x3(x, w, y, B, M, K, H, W, w_ms, w_ks, flip=False, replicate=False, addend=None, x_bs=None):
     """y = conv3x3(x) (+ addend, in the kernel's epilogue; only for layers with more than 4 channels on both sides).
     x_bs: batch stride of x in floats when x is a plane slice of a wider tensor (the I stem reads plane 2 of hvi)"""
     x_bs = K * H * W if x_bs is None else int(x_bs)
-    if CONV3_DIRECT["on"] and MATH["levels"] == 1 and CONV3_BF16X3["on"] and not replicate and x_bs == K * H * W and min(M, K) > 4 \
-            and _raw("cidnet_conv3x3_bf16_direct_supported", M, K, H, W):
-        # bf16 mode: nine shifted 1x1 products, every wave independent, no LDS (csrc/conv3p.hip)
-        n = _raw("cidnet_conv3x3_bf16_direct_ws_floats", M, K)
-
-        def prepare(buf):
-            lib().call("cidnet_conv3x3_bf16_direct_prep", _p(w), w_ms, w_ks, int(flip), _p(buf), buf.numel(), M, K, _stream())
-        pre = _prepared("c3p", w, 0, w_ms, w_ks, int(flip), M, K, n, prepare)
-        if pre is None:
-            pre = _ws(n, x.device)
-            prepare(pre)
-        lib().call("cidnet_conv3x3_bf16_direct_pre", _p(x), K * H * W, _p(pre), _p(addend), M * H * W, _p(y), M * H * W, B, M, K, H, W,
-                   _stream())
-        return
     if CONV3_BF16X3["on"] and not replicate and x_bs == K * H * W and min(M, K) > 4 and _raw("cidnet_conv3x3_bf16x3_supported", M, K) \
             and CONV3_BF16X3.get("filter", lambda *a: True)(M, K, H, W):
         n = _raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)

@@ -282,20 +282,6 @@ int cidnet_conv3x3_bf16x3_pre_lv(const float* X, long x_bs, const float* Wprep, 
                                  long y_bs, int B, int M, int K, int H, int W, int w_levels, int x_levels, void* stream);
 long cidnet_conv3x3_bf16x3_prep_blocks(int M, int K);
 int cidnet_conv3x3_bf16x3_prep_batch(const long long* table, int n, long total_blocks, void* stream);
-/* The bf16 MODE's dense 3x3 conv without LDS (csrc/conv3p.hip): both operands rounded to nearest bf16, one product per term,
- * fp32 accumulation and output (= cidnet_conv3x3_bf16x3_pre_lv with (1, 1) levels to fp32 summation order), computed as nine
- * shifted 1x1 products with every wave independent.  _prep rounds the weights into fragment order (ws: _ws_floats(M, K)
- * floats, 16-byte aligned; flip as cidnet_conv3x3), _pre convolves from them.  _supported: K in {36, 72, 144}, planes of at
- * least 64 pixels. */
-int cidnet_conv3x3_bf16_direct_supported(int M, int K, int H, int W);
-long cidnet_conv3x3_bf16_direct_ws_floats(int M, int K);
-int cidnet_conv3x3_bf16_direct_prep(const float* Wt, long w_ms, long w_ks, int flip, float* ws, long ws_floats, int M, int K,
-                                    void* stream);
-int cidnet_conv3x3_bf16_direct_pre(const float* X, long x_bs, const float* Wprep, const float* R, long r_bs, float* Y,
-                                   long y_bs, int B, int M, int K, int H, int W, void* stream);
-/* batched preparation, rows {Wt pointer, ws pointer, M, K, w_ms, w_ks, first block, flip} (see cidnet_pw_conv_bf16x3_prep_batch) */
-long cidnet_conv3x3_bf16_direct_prep_blocks(int M, int K);
-int cidnet_conv3x3_bf16_direct_prep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* Y = conv3x3(X) + R (R of Y's shape, batch stride r_bs; NULL = plain conv).  Used by the data gradient of
  * NormDownsample when its input also feeds a skip connection (net/CIDNet.py:80-81,85-86): the skip's gradient is
  * added in the epilogue instead of by a separate pass over the tensor.  Layers with <= 4 channels on a side

@@ -788,53 +788,3 @@ def test_attn_fwd_bf16_typed_qkv(dev, B, C, heads, HW):
         res.append((attn, shat, nq, nk, M))
     for a, b_ in zip(*res):
         assert torch.equal(a, b_)
-
-
-@pytest.mark.parametrize("B,M,K,H,W,flip,add", [(1, 36, 36, 8, 8, 0, False), (2, 36, 36, 24, 40, 0, True), (2, 72, 36, 16, 75, 1, True), (1, 36, 72, 20, 34, 0, False),
-                                                (1, 144, 72, 13, 150, 0, True), (2, 72, 144, 10, 15, 1, False), (1, 36, 36, 3, 23, 1, True),
-                                                (1, 190, 36, 9, 21, 0, False)])
-def test_conv3x3_bf16_direct(dev, B, M, K, H, W, flip, add):
-    """csrc/conv3p.hip, the bf16 mode's dense 3x3 conv without LDS (nine shifted 1x1 products): against the fp64 convolution
-    of the bf16-rounded operands (what is left is fp32 summation order), on shapes that exercise every border case -- rows
-    whose width is not a multiple of 4 (quads straddle rows), planes that are not a multiple of 64 pixels (pulled-back last
-    group), 3-row images (every wave touches the first and the last row), interior waves, several channel tiles per wave and
-    waves sharing a pixel group (M = 144, 190) -- forward and data-gradient (flipped, transposed weights) forms, addend;
-    every output element written (NaN prefill), rerun bit-identical, and equal to conv3x.hip's one-level form to fp32
-    summation order."""
-    from hvi_cidnet_amd import ops
-    from hvi_cidnet_amd._lib import lib
-    assert ops._raw("cidnet_conv3x3_bf16_direct_supported", M, K, H, W) == 1
-    g = torch.Generator(device=dev).manual_seed(M + K + H + W)
-    x = torch.randn(B, K, H, W, device=dev, generator=g)
-    r = torch.randn(B, M, H, W, device=dev, generator=g) if add else None
-    if flip:
-        wt = torch.randn(K, M, 3, 3, device=dev, generator=g) / (3 * K ** 0.5)
-        w_ms, w_ks = 9, 9 * M
-        ref = F.conv_transpose2d(_bf16_round(x).cpu(), _bf16_round(wt).cpu(), padding=1)
-    else:
-        wt = torch.randn(M, K, 3, 3, device=dev, generator=g) / (3 * K ** 0.5)
-        w_ms, w_ks = 9 * K, 9
-        ref = F.conv2d(_bf16_round(x).cpu(), _bf16_round(wt).cpu(), padding=1)
-    if add:
-        ref = ref + r.double().cpu()
-    n = ops._raw("cidnet_conv3x3_bf16_direct_ws_floats", M, K)
-    ws = torch.empty(n, device=dev)
-    lib().call("cidnet_conv3x3_bf16_direct_prep", ops._p(wt), w_ms, w_ks, flip, ops._p(ws), ws.numel(), M, K, ops._stream())
-    ys = []
-    for _ in range(2):
-        y = torch.full((B, M, H, W), float("nan"), device=dev)
-        lib().call("cidnet_conv3x3_bf16_direct_pre", ops._p(x), K * H * W, ops._p(ws), ops._p(r), M * H * W, ops._p(y), M * H * W, B, M, K, H, W,
-                   ops._stream())
-        ys.append(y)
-    assert not torch.isnan(ys[0]).any()
-    assert torch.equal(ys[0], ys[1])
-    err = (ys[0].double().cpu() - ref).abs().max().item()
-    assert err <= 3e-6 * ref.abs().max().item() + 1e-6, err
-    if ops._raw("cidnet_conv3x3_bf16x3_supported", M, K):
-        n2 = ops._raw("cidnet_conv3x3_bf16x3_ws_floats", M, K)
-        ws2 = torch.empty(n2, device=dev)
-        y2 = torch.empty((B, M, H, W), device=dev)
-        lib().call("cidnet_conv3x3_bf16x3_prep", ops._p(wt), w_ms, w_ks, flip, ops._p(ws2), ws2.numel(), M, K, ops._stream())
-        lib().call("cidnet_conv3x3_bf16x3_pre_lv", ops._p(x), K * H * W, ops._p(ws2), ops._p(r), M * H * W, ops._p(y2), M * H * W, B, M, K, H, W,
-                   1, 1, ops._stream())
-        assert (ys[0] - y2).abs().max().item() <= 3e-6 * ref.abs().max().item() + 1e-6

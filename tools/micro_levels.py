@@ -19,7 +19,7 @@ def timeit(fn, n=8):
         tot += e0.elapsed_time(e1)
     return 1e3 * tot / n
 
-print("== dense 3x3 (B, M, K, H, W): conv3x levels (3,3) | conv3x (1,1) | conv3p (bf16 mode, no LDS)")
+print("== dense 3x3 (B, M, K, H, W): levels (3,3) | (1,1)")
 for (B, M, K, H, W) in [(8, 36, 36, 400, 600), (8, 36, 36, 200, 300), (8, 72, 36, 200, 300), (8, 36, 72, 200, 300), (8, 144, 72, 100, 150), (8, 72, 144, 100, 150), (8, 72, 144, 50, 75)]:
     x = torch.randn(B, K, H, W, device=dev); w = torch.randn(M, K, 3, 3, device=dev) / (3 * K ** 0.5); y = torch.empty(B, M, H, W, device=dev)
     n = ops._raw("cidnet_conv3x3_bf16x3_ws_floats", M, K); ws = torch.empty(n, device=dev)
@@ -28,10 +28,7 @@ for (B, M, K, H, W) in [(8, 36, 36, 400, 600), (8, 36, 36, 200, 300), (8, 72, 36
     for lv in (3, 1):
         t[lv] = timeit(lambda: lib().call("cidnet_conv3x3_bf16x3_pre_lv", _p(x), K * H * W, _p(ws), None, 0, _p(y), M * H * W, B, M, K, H, W, lv, lv, _stream()))
     by = (K + M) * 4.0 * H * W * B
-    n3 = ops._raw("cidnet_conv3x3_bf16_direct_ws_floats", M, K); ws3 = torch.empty(n3, device=dev)
-    lib().call("cidnet_conv3x3_bf16_direct_prep", _p(w), 9 * K, 9, 0, _p(ws3), n3, M, K, _stream())
-    tp = timeit(lambda: lib().call("cidnet_conv3x3_bf16_direct_pre", _p(x), K * H * W, _p(ws3), None, 0, _p(y), M * H * W, B, M, K, H, W, _stream()))
-    print(f"  {(B, M, K, H, W)}: {t[3]:7.1f} us ({by / t[3] / 1e3:6.0f} GB/s) | {t[1]:7.1f} us ({by / t[1] / 1e3:6.0f} GB/s) | {tp:7.1f} us ({by / tp / 1e3:6.0f} GB/s)", flush=True)
+    print(f"  {(B, M, K, H, W)}: {t[3]:7.1f} us ({by / t[3] / 1e3:6.0f} GB/s) | {t[1]:7.1f} us ({by / t[1] / 1e3:6.0f} GB/s)", flush=True)
 
 print("== 3x3 weight gradient (B, M, N, H, W): levels 3 | 1")
 for (B, M, N, H, W) in [(8, 36, 36, 400, 600), (8, 72, 36, 200, 300), (8, 144, 72, 100, 150), (8, 72, 144, 50, 75)]:
