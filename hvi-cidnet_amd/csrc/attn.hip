@@ -309,6 +309,29 @@ __global__ void sum_rows_kernel(const float* __restrict__ in, int n_red, long n,
   out[i] = t;
 }
 
+// the same sum for MANY rows (hundreds of per-block partials, e.g. cidnet_modulate_bwd's): one thread per output walking all
+// rows is a chain of n_red dependent-latency loads (944 rows x 36 outputs: 218 us).  Here a block owns 8 outputs and 32 lanes
+// per output stride over the rows, two partial sums each; the 32 partials are added through LDS in fixed order.
+__global__ __launch_bounds__(256) void sum_rows_wide_kernel(const float* __restrict__ in, int n_red, long n, float* __restrict__ out) {
+  __shared__ float part[32][9];
+  const int ex = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const long i = (long)blockIdx.x * 8 + ex;
+  float t0 = 0.f, t1 = 0.f;
+  if (i < n) {
+    int r = sl;
+    for (; r + 32 < n_red; r += 64) { t0 += in[(long)r * n + i]; t1 += in[(long)(r + 32) * n + i]; }
+    if (r < n_red) t0 += in[(long)r * n + i];
+  }
+  part[sl][ex] = t0 + t1;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float t = part[0][ex];
+#pragma unroll
+    for (int q = 1; q < 32; ++q) t += part[q][ex];
+    out[i] = t;
+  }
+}
+
 inline int gram_pch(long HW) { return HW >= 16384 ? 2048 : 512; }
 
 }  // namespace
@@ -371,7 +394,10 @@ int cidnet_attn_bwd(const float* dM, const float* Wp, const float* attn, const f
 
 int cidnet_sum_rows(const float* in, int n_red, long n, float* out, void* stream) {
   CIDNET_CHECK_ARG(in && out && n_red > 0 && n > 0);
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n_red, n, out);
+  if (n_red > 64)
+    hipLaunchKernelGGL(sum_rows_wide_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, in, n_red, n, out);
+  else
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n_red, n, out);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }

@@ -260,41 +260,56 @@ __global__ __launch_bounds__(kThreads) void modulate_fwd_kernel(const float* __r
 }
 
 // backward: gvin = gvout * keep;  gk = gvout * v * keep * (1 - keep);  gnm[b][p] = sum_c gk * ws[c];
-// gws[c] partial per (b,c) = sum_p gk * nm   -- one block per (b, pixel chunk), channels looped
+// gws[c] partial per (b, pixel chunk) = sum_p gk * nm.
+// A block is 32 pixel quads x 8 channel lanes (thread = quad + 32 * channel lane; channel lane cl walks channels cl, cl + 8, ...):
+// at the 50x75 level a lane per quad looping over all 144 channels, with a block reduction (two barriers) per channel, left
+// 64 blocks on the chip for 306 us.  The per-channel sum over the block's 32 quads is a 5-step shuffle inside a half wave (no
+// LDS, no barrier); the sum over the 8 channel lanes for gnm goes through LDS once, in fixed order.
+constexpr int kModQ = 32, kModCL = kThreads / kModQ;
 __global__ __launch_bounds__(kThreads) void modulate_bwd_kernel(const float* __restrict__ vin, long vin_bs,
                                                                 const float* __restrict__ nm, const float* __restrict__ ws,
                                                                 const float* __restrict__ gvout, float* __restrict__ gvin,
                                                                 long gvin_bs, float* __restrict__ gnm, float* __restrict__ gws_part,
                                                                 int B, int C, long HW) {
-  __shared__ float red[kThreads / 64];
+  __shared__ f32x4 red[kModCL][kModQ];
   const int b = blockIdx.y;
+  const int ql = threadIdx.x & (kModQ - 1), cl = threadIdx.x / kModQ;
   const long nq = (HW + 3) >> 2;
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long q = (long)blockIdx.x * kModQ + ql;
   const bool live = q < nq;
   const long p = q << 2;
   const int n = live ? ((HW - p >= 4) ? 4 : (int)(HW - p)) : 0;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, gn = s;
   if (live) s = ld4(nm + b * HW, p, n);
-  for (int c = 0; c < C; ++c) {
+  for (int c = cl; c < C; c += kModCL) {
     float part = 0.f;
     if (live) {
       const f32x4 v = ld4(vin + b * vin_bs + (long)c * HW, p, n);
       const f32x4 g = ld4(gvout + ((long)b * C + c) * HW, p, n);
+      const float wc = ws[c];
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float k = sigmoidf(ws[c] * s[e]);
+        const float k = sigmoidf(wc * s[e]);
         o[e] = g[e] * k;
         const float gk = g[e] * v[e] * k * (1.f - k);
-        gn[e] += gk * ws[c];
+        gn[e] += gk * wc;
         if (e < n) part += gk * s[e];
       }
       st4(gvin + b * gvin_bs + (long)c * HW, p, n, o);
     }
-    const float r = block_sum(part, red);
-    if (threadIdx.x == 0) gws_part[((long)b * gridDim.x + blockIdx.x) * C + c] = r;
+#pragma unroll
+    for (int m = 1; m < kModQ; m <<= 1) part += __shfl_xor(part, m, 64);      // the 32 quads of this channel lane: one half wave
+    if (ql == 0) gws_part[((long)b * gridDim.x + blockIdx.x) * C + c] = part;
   }
-  if (live) st4(gnm + b * HW, p, n, gn);
+  red[cl][ql] = gn;
+  __syncthreads();
+  if (cl == 0 && live) {
+    f32x4 t = red[0][ql];
+#pragma unroll
+    for (int i = 1; i < kModCL; ++i) t += red[i][ql];
+    st4(gnm + b * HW, p, n, t);
+  }
 }
 
 // ---- out = nm * a + (1 - nm) * d ;  backward: ga = g*nm, gd = g*(1-nm), gnm = sum_c g*(a - d) -------
@@ -312,25 +327,37 @@ __global__ __launch_bounds__(kThreads) void blend_fwd_kernel(const float* __rest
   }
 }
 
+// block = 32 pixel quads x 8 channel lanes, as modulate_bwd_kernel (a lane per quad looping over 144 channels took 353 us at 50x75)
 __global__ __launch_bounds__(kThreads) void blend_bwd_kernel(const float* __restrict__ a, const float* __restrict__ d,
                                                              const float* __restrict__ nm, const float* __restrict__ g,
                                                              float* __restrict__ ga, float* __restrict__ gd, float* __restrict__ gnm,
                                                              int B, int C, long HW) {
+  __shared__ f32x4 red[kModCL][kModQ];
+  const int b = blockIdx.y;
+  const int ql = threadIdx.x & (kModQ - 1), cl = threadIdx.x / kModQ;
   const long nq = (HW + 3) >> 2;
-  const long total = (long)B * nq;
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const long b = it / nq, p = (it - b * nq) << 2;
-    const int n = (HW - p >= 4) ? 4 : (int)(HW - p);
+  const long q = (long)blockIdx.x * kModQ + ql;
+  const bool live = q < nq;
+  const long p = q << 2;
+  const int n = live ? ((HW - p >= 4) ? 4 : (int)(HW - p)) : 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
     const f32x4 s = ld4(nm + b * HW, p, n);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < C; ++c) {
+    for (int c = cl; c < C; c += kModCL) {
       const long o = ((long)b * C + c) * HW;
       const f32x4 gg = ld4(g + o, p, n);
       acc += gg * (ld4(a + o, p, n) - ld4(d + o, p, n));
       st4(ga + o, p, n, gg * s);
       st4(gd + o, p, n, gg * (1.f - s));
     }
-    st4(gnm + b * HW, p, n, acc);
+  }
+  red[cl][ql] = acc;
+  __syncthreads();
+  if (cl == 0 && live) {
+    f32x4 t = red[0][ql];
+#pragma unroll
+    for (int i = 1; i < kModCL; ++i) t += red[i][ql];
+    st4(gnm + b * HW, p, n, t);
   }
 }
 
@@ -493,13 +520,13 @@ int cidnet_modulate_fwd(const float* vin, long vin_bs, const float* nm, const fl
   return CIDNET_OK;
 }
 
-long cidnet_modulate_bwd_ws_floats(int B, int C, long HW) { return (long)B * (((HW + 3) / 4 + kThreads - 1) / kThreads) * C; }
+long cidnet_modulate_bwd_ws_floats(int B, int C, long HW) { return (long)B * (((HW + 3) / 4 + kModQ - 1) / kModQ) * C; }
 
-/* gws_part: (B * nchunk, C) partials, nchunk = ceil(ceil(HW/4)/256); the caller sums rows (cidnet_sum_rows) */
+/* gws_part: (B * nchunk, C) partials, nchunk = ceil(ceil(HW/4)/32); the caller sums rows (cidnet_sum_rows) */
 int cidnet_modulate_bwd(const float* vin, long vin_bs, const float* nm, const float* ws, const float* gvout, float* gvin,
                         long gvin_bs, float* gnm, float* gws_part, int B, int C, long HW, void* stream) {
   CIDNET_CHECK_ARG(vin && nm && ws && gvout && gvin && gnm && gws_part && B > 0 && C > 0 && HW > 0);
-  const unsigned nchunk = (unsigned)(((HW + 3) / 4 + kThreads - 1) / kThreads);
+  const unsigned nchunk = (unsigned)(((HW + 3) / 4 + kModQ - 1) / kModQ);
   hipLaunchKernelGGL(modulate_bwd_kernel, dim3(nchunk, (unsigned)B), dim3(kThreads), 0, (hipStream_t)stream, vin, vin_bs, nm, ws,
                      gvout, gvin, gvin_bs, gnm, gws_part, B, C, HW);
   CIDNET_LAUNCH_STATUS();
@@ -517,8 +544,9 @@ int cidnet_blend_fwd(const float* a, const float* d, const float* nm, float* out
 int cidnet_blend_bwd(const float* a, const float* d, const float* nm, const float* g, float* ga, float* gd, float* gnm, int B, int C,
                      long HW, void* stream) {
   CIDNET_CHECK_ARG(a && d && nm && g && ga && gd && gnm && B > 0 && C > 0 && HW > 0);
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid_for((long)B * ((HW + 3) / 4))), dim3(kThreads), 0, (hipStream_t)stream, a, d, nm, g,
-                     ga, gd, gnm, B, C, HW);
+  const unsigned nchunk = (unsigned)(((HW + 3) / 4 + kModQ - 1) / kModQ);
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(nchunk, (unsigned)B), dim3(kThreads), 0, (hipStream_t)stream, a, d, nm, g, ga, gd, gnm, B, C,
+                     HW);
   CIDNET_LAUNCH_STATUS();
   return CIDNET_OK;
 }
