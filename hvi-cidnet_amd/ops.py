@@ -54,7 +54,7 @@ def _p(t):
 
 # torch.cuda.current_stream() builds a Stream object through three Python layers (~8 us; ~500 calls per training step = a
 # quarter of the host's enqueue time).  The raw handle comes from one C call; the Python form stays as the fallback.
-_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("CIDNET_PY_STREAM") != "1" else None
 _CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 
 
