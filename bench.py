@@ -602,7 +602,7 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_TRAFFIC_FILE = "profiles/r04_m_pmc_traffic_by_family.json"
+PMC_TRAFFIC_FILE = "profiles/r04_z_pmc_traffic_by_family.json"
 
 
 def pmc_traffic(family):
