@@ -176,12 +176,14 @@ def test_trainer_rccl_path_on_one_rank(dev, monkeypatch):
         ops.enable_wgrad_stream(False)
 
 
-def test_trainer_graph_replay_equals_eager(dev):
+@pytest.mark.parametrize("chans,shape", [((12, 12, 24, 48), (2, 3, 32, 48)), ((36, 36, 72, 144), (1, 3, 64, 96))])
+def test_trainer_graph_replay_equals_eager(dev, chans, shape):
     """forward + loss + backward replayed as one hipGraph (three streams captured) must give the eager step's
-    gradients and parameter updates bit for bit, step after step (new inputs are copied into the static buffers)."""
+    gradients and parameter updates bit for bit, step after step (new inputs are copied into the static buffers).  The
+    full-width case runs the split-product kernels inside the capture: their prepared weight operands are cache hits there
+    (created by the eager passes before the capture) and are refreshed after every Adam update outside the graph."""
     from hvi_cidnet_amd import ops
     from hvi_cidnet_amd.dp import DataParallelTrainer
-    chans, shape = (12, 12, 24, 48), (2, 3, 32, 48)
     batches = [(O.synthetic_batch(51 + i, shape).to(dev), O.synthetic_batch(61 + i, shape).to(dev)) for i in range(3)]
     res = []
     for use_graph in (False, True):
