@@ -153,6 +153,9 @@ def pw_work(name, args):
     if name in ("cidnet_pw_conv_bf16x3_pre", "cidnet_pw_conv_bf16x3_pre_lv"):   # (X, x_bs, Wprep, per_sample, Y, y_bs, R, r_bs, B, M, K, HW, [w_levels, x_levels,] stream)
         R, B, M, K, HW = args[6], args[8], args[9], args[10], args[11]
         return 2.0 * M * K * HW * B, (K + M + (M if R is not None else 0)) * 4 * HW * B
+    if name == "cidnet_pw_conv_bf16x3_pre_t":   # (X, x_dt, x_bs, Wprep, per_sample, Y, y_dt, y_bs, R, r_bs, B, M, K, HW, w_levels, x_levels, stream)
+        x_dt, y_dt, R, B, M, K, HW = args[1], args[6], args[8], args[10], args[11], args[12], args[13]
+        return 2.0 * M * K * HW * B, (K * es(x_dt) + M * es(y_dt) + (M * 4 if R is not None else 0)) * HW * B
     if name == "cidnet_pw_conv_up_prelu":  # (skip, x_bs, Wt, w_ms, w_ks, Z, slope, Y, Ypre, B, M, K, zh, zw, stream)
         Ypre, B, M, K, zh, zw = args[8], args[9], args[10], args[11], args[12], args[13]
         hw = 4 * zh * zw
@@ -545,7 +548,7 @@ def main():
         # the family that bounds the step: the 1x1 convs and their weight gradients
         pw = [(pw_work(name, args), e0.elapsed_time(e1)) for name, args, e0, e1 in timer.rec if pw_work(name, args) is not None]
         pw_fl, pw_by, pw_ms = sum(w[0] for w, _ in pw), sum(w[1] for w, _ in pw), sum(t for _, t in pw)
-        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3[_pre], cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t, cidnet_pw_bwd_fused)",
+        roof_pw = {"bound": "hbm", "kernel": "1x1-conv family (cidnet_pw_conv_t, cidnet_pw_conv_bf16x3[_pre, _pre_lv, _pre_t], cidnet_pw_conv_up_prelu, cidnet_pw_wgrad_t, cidnet_pw_bwd_fused)",
                    "achieved": round(pw_by / (pw_ms * 1e-3) / 1e9, 1) if pw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": round(pw_by / (pw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if pw_ms > 0 else 0.0,
                    "tflops": round(pw_fl / (pw_ms * 1e-3) / 1e12, 2) if pw_ms > 0 else 0.0,

@@ -47,6 +47,17 @@ def test_work_formulas_follow_the_header_argument_order():
     assert [a[i] for i in (1, 4, 12, 13, 14, 15)] == ["dy_dt", "x_dt", "B", "M", "N", "HW"]
     a = names("cidnet_pw_conv_t")
     assert [a[i] for i in (1, 8, 10, 12, 13, 14, 15)] == ["x_dt", "y_dt", "R", "B", "M", "K", "HW"]
-    # the typed 1x1 entry point the step uses: bench.pw_work must know it
+    a = names("cidnet_pw_conv_bf16x3_pre_t")
+    assert [a[i] for i in (1, 6, 8, 10, 11, 12, 13)] == ["x_dt", "y_dt", "R", "B", "M", "K", "HW"]
+    # the typed 1x1 entry point the step uses (ops.pw_conv_bf16x3): bench.pw_work must know it -- for a while it did not, and the
+    # 1x1 family's roofline silently lost its largest member
     fl, by = b.pw_work("cidnet_pw_conv_bf16x3_pre_t", (0, 0, 0, 0, 0, 0, 0, 0, None, 0, 8, 36, 95, 60000, 3, 3, 0))
     assert fl == 2.0 * 36 * 95 * 60000 * 8 and by == (95 * 4 + 36 * 4) * 60000 * 8
+    # every 1x1 entry point ops.py calls is priced
+    import re
+    src = open(os.path.join(ROOT, "hvi-cidnet_amd", "ops.py")).read()
+    called = set(re.findall(r'lib\(\)\.call\("(cidnet_pw_(?:conv|wgrad|bwd)[a-z0-9_]*)"', src))
+    called -= {n for n in called if n.endswith("_prep") or n.endswith("_prep_batch")}
+    for n in called:
+        nargs = len(protos[n][1])
+        assert b.pw_work(n, tuple([0] * nargs)) is not None, f"bench.pw_work does not price {n}"
