@@ -87,6 +87,10 @@ def _check_code_objects(verbose):
     """A freshly linked library must pass the static code-object checks (codeobj_check.py: no packed-fp32 / SDWA
     instructions, no inline-assembly load read before its wait) -- a compiler or flag change (CIDNET_EXTRA_FLAGS) that
     reintroduces either fails the BUILD, not only a test.  CIDNET_ALLOW_PACKED builds (A/B measurements) skip check 1."""
+    if os.environ.get("CIDNET_SKIP_CODEOBJ_CHECK") == "1":      # explicit opt-out (a box without llvm-objdump); tests still check
+        if verbose:
+            print("[build] code-object checks skipped (CIDNET_SKIP_CODEOBJ_CHECK=1)")
+        return
     sys.path.insert(0, HERE)
     try:
         import codeobj_check
